@@ -1,0 +1,174 @@
+/*
+ * rccl_amd.h — C ABI of the MI355X-native collective engine.
+ *
+ * The entry points below carry the names, argument order, argument meaning and
+ * error convention of the reference's public header (ROCm/rccl src/nccl.h.in), so
+ * that code written against <rccl/rccl.h> for ncclAllReduce / ncclReduceScatter /
+ * ncclAllGather and the communicator lifecycle links against librccl_amd.so
+ * unchanged.  Each declaration cites the reference line it replaces.
+ *
+ * Plain C: pointers, sizes and enums only.  A hipStream_t is passed as an opaque
+ * pointer, so this header needs no HIP include.
+ */
+#ifndef RCCL_AMD_H_
+#define RCCL_AMD_H_
+
+#include <limits.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Reports the NCCL API level this library tracks (reference: RCCL 2.21.5). */
+#define RCCL_AMD_NCCL_VERSION_CODE 22105
+
+/* Same declaration as <hip/hip_runtime_api.h>; repeating an identical typedef is legal in C11 and C++. */
+typedef struct ihipStream_t* hipStream_t;
+
+/* nccl.h.in:36-42 */
+typedef struct ncclComm* ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+
+/* nccl.h.in:50-60 */
+typedef enum {
+  ncclSuccess = 0,
+  ncclUnhandledCudaError = 1,
+  ncclSystemError = 2,
+  ncclInternalError = 3,
+  ncclInvalidArgument = 4,
+  ncclInvalidUsage = 5,
+  ncclRemoteError = 6,
+  ncclInProgress = 7,
+  ncclNumResults = 8
+} ncclResult_t;
+
+/* nccl.h.in:63-99 */
+#define NCCL_CONFIG_UNDEF_INT INT_MIN
+#define NCCL_CONFIG_UNDEF_PTR NULL
+typedef struct ncclConfig_v21700 {
+  size_t size;
+  unsigned int magic;
+  unsigned int version;
+  int blocking;
+  int cgaClusterSize;
+  int minCTAs;
+  int maxCTAs;
+  const char* netName;
+  int splitShare;
+} ncclConfig_t;
+#define NCCL_CONFIG_INITIALIZER { sizeof(ncclConfig_t), 0xcafebeef, RCCL_AMD_NCCL_VERSION_CODE, \
+  NCCL_CONFIG_UNDEF_INT, NCCL_CONFIG_UNDEF_INT, NCCL_CONFIG_UNDEF_INT, NCCL_CONFIG_UNDEF_INT,   \
+  NCCL_CONFIG_UNDEF_PTR, NCCL_CONFIG_UNDEF_INT }
+
+/* nccl.h.in:341-360 */
+typedef enum { ncclNumOps_dummy = 5 } ncclRedOp_dummy_t;
+typedef enum {
+  ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4,
+  ncclNumOps = 5,
+  ncclMaxRedOp = 0x7fffffff >> (32 - 8 * sizeof(ncclRedOp_dummy_t))
+} ncclRedOp_t;
+
+/* nccl.h.in:364-377.  The two fp8 types are accepted by ncclAllGather (a byte
+ * copy) and rejected with ncclInvalidArgument by the reducing collectives. */
+typedef enum {
+  ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3,
+  ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7,
+  ncclFloat64 = 8, ncclDouble = 8, ncclBfloat16 = 9, ncclFp8E4M3 = 10, ncclFp8E5M2 = 11,
+  ncclNumTypes = 12
+} ncclDataType_t;
+
+/* nccl.h.in:393-396 */
+typedef enum { ncclScalarDevice = 0, ncclScalarHostImmediate = 1 } ncclScalarResidence_t;
+
+/* ---- version / errors ------------------------------------------------------ */
+ncclResult_t ncclGetVersion(int* version);                                   /* nccl.h.in:121 */
+const char*  ncclGetErrorString(ncclResult_t result);                        /* nccl.h.in:262 */
+const char*  ncclGetLastError(ncclComm_t comm);                              /* nccl.h.in:268 */
+ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError); /* nccl.h.in:279 */
+
+/* ---- communicator lifecycle ------------------------------------------------ */
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);                        /* nccl.h.in:144 */
+ncclResult_t ncclCommInitRankConfig(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank,
+                                    ncclConfig_t* config);                   /* nccl.h.in:161 */
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank); /* nccl.h.in:177 */
+ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist); /* nccl.h.in:193 */
+ncclResult_t ncclCommFinalize(ncclComm_t comm);                              /* nccl.h.in:207 */
+ncclResult_t ncclCommDestroy(ncclComm_t comm);                               /* nccl.h.in:217 */
+ncclResult_t ncclCommAbort(ncclComm_t comm);                                 /* nccl.h.in:228 */
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);               /* nccl.h.in:295 */
+ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device);           /* nccl.h.in:306 */
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);             /* nccl.h.in:317 */
+ncclResult_t ncclMemAlloc(void** ptr, size_t size);                          /* nccl.h.in:105 */
+ncclResult_t ncclMemFree(void* ptr);                                         /* nccl.h.in:108 */
+
+/* ---- custom pre-multiply-sum operator --------------------------------------- */
+ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype,
+                                      ncclScalarResidence_t residence, ncclComm_t comm); /* nccl.h.in:412 */
+ncclResult_t ncclRedOpDestroy(ncclRedOp_t op, ncclComm_t comm);              /* nccl.h.in:425 */
+
+/* ---- the hot path ----------------------------------------------------------- */
+/* Each call returns once the operation is enqueued on `stream` (nccl.h.in:435-438).
+ * In place when sendbuff == recvbuff (all-reduce), recvbuff == sendbuff + rank*recvcount
+ * (reduce-scatter) or sendbuff == recvbuff + rank*sendcount (all-gather). */
+ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
+                           ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);        /* nccl.h.in:519-520 */
+ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount,
+                               ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm,
+                               hipStream_t stream);                                      /* nccl.h.in:542-544 */
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount,
+                           ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream); /* nccl.h.in:565-566 */
+ncclResult_t ncclGroupStart(void);                                           /* nccl.h.in:808 */
+ncclResult_t ncclGroupEnd(void);                                             /* nccl.h.in:818 */
+
+/* ---- declared by the reference, outside this library's path ----------------- */
+/* These exist so that a program using them still links; each returns
+ * ncclInvalidUsage and records a message for ncclGetLastError. */
+ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
+                        ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream);  /* nccl.h.in:458 */
+ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
+                           int root, ncclComm_t comm, hipStream_t stream);               /* nccl.h.in:499 */
+ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
+                       hipStream_t stream);                                              /* nccl.h.in:478 */
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer,
+                      ncclComm_t comm, hipStream_t stream);                              /* nccl.h.in:587 */
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,
+                      hipStream_t stream);                                               /* nccl.h.in:609 */
+ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm,
+                           ncclConfig_t* config);                                        /* nccl.h.in:247 */
+
+/* ---- extensions (no counterpart in nccl.h.in) -------------------------------- */
+
+/* Local N-source reduce-copy on the current device: dst[i] = src[0][i] (op) ... (op) src[nsrc-1][i],
+ * folded left to right in element type `datatype`.  This is the kernel every reducing hop runs
+ * (the role of reduceCopy, src/device/common_kernel.h:185-265); exported for parity tests and for
+ * measuring it against the HBM roofline.  1 <= nsrc <= 8.  Enqueued on `stream`. */
+ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, size_t count,
+                               ncclDataType_t datatype, ncclRedOp_t op, hipStream_t stream);
+
+/* Ring schedule synthesis for a single node whose GPUs are joined by direct xGMI links
+ * (the job of the ring search + pre-baked models, src/graph/search.cc:919-986,
+ * src/graph/rome_models.cc:549-560).  `adj` is an ngpus x ngpus 0/1 matrix of direct links.
+ * Writes up to maxRings rings of ngpus ranks each into `rings` (row-major) and their number into
+ * *nrings.  Every ring is a Hamiltonian cycle over links of `adj`; over the whole set each directed
+ * link is used the same number of times when such a set exists. */
+ncclResult_t rcclAmdTopoRings(int ngpus, const int* adj, int maxRings, int* rings, int* nrings);
+
+/* Parses a topology XML in the reference's format (tools/topo_expl/models/*.xml, written by
+ * src/graph/xml.cc) and fills the ngpus x ngpus direct-xGMI adjacency matrix.  `adj` must hold
+ * maxGpus*maxGpus ints; *ngpus receives the GPU count. */
+ncclResult_t rcclAmdTopoParseXml(const char* xmlText, int maxGpus, int* adj, int* ngpus);
+
+/* What the planner would choose for a collective on `comm`: algorithm (0 direct all-pairs,
+ * 1 ring, 2 chain tree), protocol (0 simple, 1 low-latency), channels, chunk elements.
+ * coll: 0 all-reduce, 1 reduce-scatter, 2 all-gather. */
+ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll,
+                             size_t count, ncclDataType_t datatype, int* algo, int* proto,
+                             int* nChannels, size_t* chunkElems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCCL_AMD_H_ */

@@ -1,0 +1,193 @@
+// The exported C ABI (include/rccl_amd.h).  Every symbol forwards to an internal function
+// so that calls made inside this library never bind to another RCCL loaded in the process.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "comm.h"
+#include "debug.h"
+#include "launch.h"
+
+#define RA_API extern "C" __attribute__((visibility("default")))
+
+RA_API ncclResult_t ncclGetVersion(int* version) {
+  if (!version) return ncclInvalidArgument;
+  *version = RCCL_AMD_NCCL_VERSION_CODE;
+  return ncclSuccess;
+}
+
+RA_API const char* ncclGetErrorString(ncclResult_t r) {
+  // texts of src/init.cc ncclGetErrorString
+  switch (r) {
+    case ncclSuccess: return "no error";
+    case ncclUnhandledCudaError: return "unhandled cuda error (run with NCCL_DEBUG=INFO for details)";
+    case ncclSystemError: return "unhandled system error (run with NCCL_DEBUG=INFO for details)";
+    case ncclInternalError: return "internal error - please report this issue to the NCCL developers";
+    case ncclInvalidArgument: return "invalid argument (run with NCCL_DEBUG=WARN for details)";
+    case ncclInvalidUsage: return "invalid usage (run with NCCL_DEBUG=WARN for details)";
+    case ncclRemoteError: return "remote process exited or there was a network error";
+    case ncclInProgress: return "NCCL operation in progress";
+    default: return "unknown result code";
+  }
+}
+
+RA_API const char* ncclGetLastError(ncclComm_t) { return raLastError(); }
+
+RA_API ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError) {
+  RA_CHECK(raCommCheck(comm, "ncclCommGetAsyncError"));
+  if (!asyncError) return ncclInvalidArgument;
+  *asyncError = raCommPollError(comm);
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  if (!id) { RA_WARN("ncclGetUniqueId: uniqueId is NULL"); return ncclInvalidArgument; }
+  return raBootstrapCreate(id);
+}
+
+RA_API ncclResult_t ncclCommInitRankConfig(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank, ncclConfig_t* config) {
+  if (raGroupDepth() > 0) {
+    int dev = 0;
+    RA_HIP(hipGetDevice(&dev));
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    raGroupAddInit(comm, nranks, id, rank, config, dev);
+    return ncclSuccess;
+  }
+  return raCommInitRank(comm, nranks, id, rank, config);
+}
+RA_API ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
+  return ncclCommInitRankConfig(comm, nranks, id, rank, nullptr);
+}
+RA_API ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist) { return raCommInitAll(comm, ndev, devlist); }
+
+RA_API ncclResult_t ncclCommFinalize(ncclComm_t comm) {
+  RA_CHECK(raCommCheck(comm, "ncclCommFinalize"));
+  if (comm->haveLast) {
+    int old = 0;
+    (void)hipGetDevice(&old);
+    (void)hipSetDevice(comm->device);
+    hipError_t e = hipStreamSynchronize(comm->lastStream);
+    (void)hipSetDevice(old);
+    if (e != hipSuccess) return ncclUnhandledCudaError;
+  }
+  comm->finalized = true;
+  return raCommPollError(comm);
+}
+RA_API ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+  if (comm == nullptr) return ncclSuccess;   // src/init.cc: destroying NULL is a no-op
+  return raCommDestroy(comm, false);
+}
+RA_API ncclResult_t ncclCommAbort(ncclComm_t comm) {
+  if (comm == nullptr) return ncclSuccess;
+  return raCommDestroy(comm, true);
+}
+RA_API ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  RA_CHECK(raCommCheck(comm, "ncclCommCount"));
+  if (!count) return ncclInvalidArgument;
+  *count = comm->nRanks;
+  return ncclSuccess;
+}
+RA_API ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device) {
+  RA_CHECK(raCommCheck(comm, "ncclCommCuDevice"));
+  if (!device) return ncclInvalidArgument;
+  *device = comm->device;
+  return ncclSuccess;
+}
+RA_API ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+  RA_CHECK(raCommCheck(comm, "ncclCommUserRank"));
+  if (!rank) return ncclInvalidArgument;
+  *rank = comm->rank;
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t ncclMemAlloc(void** ptr, size_t size) {
+  if (!ptr) return ncclInvalidArgument;
+  RA_HIP(hipMalloc(ptr, size));
+  return ncclSuccess;
+}
+RA_API ncclResult_t ncclMemFree(void* ptr) {
+  RA_HIP(hipFree(ptr));
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype,
+                                             ncclScalarResidence_t residence, ncclComm_t comm) {
+  // src/enqueue.cc:2219-2270
+  RA_CHECK(raCommCheck(comm, "ncclRedOpCreatePreMulSum"));
+  if (!op || !scalar) return ncclInvalidArgument;
+  const size_t es = raTypeSize(datatype);
+  if (es == 0 || datatype == ncclFp8E4M3 || datatype == ncclFp8E5M2) { RA_WARN("ncclRedOpCreatePreMulSum: unsupported datatype %d", datatype); return ncclInvalidArgument; }
+  for (int i = 0; i < RA_MAX_USER_OPS; i++) {
+    if (comm->userOps[i].used) continue;
+    RaUserOp& u = comm->userOps[i];
+    u.used = true; u.dtype = datatype; u.arg = 0; u.argPtr = nullptr;
+    if (residence == ncclScalarHostImmediate) memcpy(&u.arg, scalar, es);
+    else u.argPtr = scalar;
+    *op = (ncclRedOp_t)((int)ncclNumOps + i);
+    return ncclSuccess;
+  }
+  RA_WARN("ncclRedOpCreatePreMulSum: too many live custom operators");
+  return ncclInvalidUsage;
+}
+RA_API ncclResult_t ncclRedOpDestroy(ncclRedOp_t op, ncclComm_t comm) {
+  RA_CHECK(raCommCheck(comm, "ncclRedOpDestroy"));
+  const int ix = (int)op - (int)ncclNumOps;
+  if (ix < 0 || ix >= RA_MAX_USER_OPS || !comm->userOps[ix].used) { RA_WARN("ncclRedOpDestroy: operator %d is not a live custom operator", (int)op); return ncclInvalidArgument; }
+  comm->userOps[ix].used = false;
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
+                                  ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
+  RaCollArgs a{RA_COLL_ALLREDUCE, sendbuff, recvbuff, count, (int)datatype, (int)op, comm, stream};
+  return raEnqueue(a);
+}
+RA_API ncclResult_t ncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype,
+                                      ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) {
+  RaCollArgs a{RA_COLL_REDUCESCATTER, sendbuff, recvbuff, recvcount, (int)datatype, (int)op, comm, stream};
+  return raEnqueue(a);
+}
+RA_API ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype,
+                                  ncclComm_t comm, hipStream_t stream) {
+  RaCollArgs a{RA_COLL_ALLGATHER, sendbuff, recvbuff, sendcount, (int)datatype, (int)ncclSum, comm, stream};
+  return raEnqueue(a);
+}
+RA_API ncclResult_t ncclGroupStart(void) { return raGroupStart(); }
+RA_API ncclResult_t ncclGroupEnd(void) { return raGroupEnd(); }
+
+static ncclResult_t outOfScope(const char* name) {
+  RA_WARN("%s is outside this library's path (all-reduce, reduce-scatter, all-gather)", name);
+  return ncclInvalidUsage;
+}
+RA_API ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclReduce"); }
+RA_API ncclResult_t ncclBroadcast(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclBroadcast"); }
+RA_API ncclResult_t ncclBcast(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclBcast"); }
+RA_API ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclSend"); }
+RA_API ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclRecv"); }
+RA_API ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) { return outOfScope("ncclCommSplit"); }
+
+RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, size_t count, ncclDataType_t datatype,
+                                      ncclRedOp_t op, hipStream_t stream) {
+  if (!dst || !srcs || nsrc < 1 || nsrc > RA_MAX_SRCS) { RA_WARN("rcclAmdReduceCopy: 1..%d sources", RA_MAX_SRCS); return ncclInvalidArgument; }
+  if (datatype < 0 || datatype > ncclBfloat16 || op < 0 || op > ncclMin) { RA_WARN("rcclAmdReduceCopy: unsupported type/op"); return ncclInvalidArgument; }
+  if (count == 0) return ncclSuccess;
+  const size_t bytes = count * raTypeSize(datatype);
+  size_t grid = (bytes + 256 * 64 - 1) / (256 * 64);
+  if (grid > 2048) grid = 2048;
+  static const int devOps[] = {RA_OP_SUM, RA_OP_PROD, RA_OP_MAX, RA_OP_MIN};
+  hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, count, datatype, devOps[op], (int)grid, stream);
+  if (e != hipSuccess) { RA_WARN("rcclAmdReduceCopy: launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll, size_t count, ncclDataType_t datatype, int* algo, int* proto,
+                                    int* nChannels, size_t* chunkElems) {
+  RA_CHECK(raCommCheck(comm, "rcclAmdPlanInfo"));
+  if (coll < 0 || coll > RA_COLL_ALLGATHER) return ncclInvalidArgument;
+  RaPlan p;
+  RA_CHECK(raPlan(comm, coll, count, datatype, &p));
+  if (algo) *algo = p.algo;
+  if (proto) *proto = p.proto;
+  if (nChannels) *nChannels = p.nChannels;
+  if (chunkElems) *chunkElems = p.chunkElems;
+  return ncclSuccess;
+}

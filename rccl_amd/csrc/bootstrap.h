@@ -1,0 +1,28 @@
+// Out-of-band rendezvous between the ranks of one communicator.
+//
+// Role of the reference's bootstrap (src/bootstrap.cc:244-333 bootstrapInit, ring
+// all-gather and intra-node barrier): the ncclUniqueId names a TCP endpoint; every rank
+// connects to it and the ranks then exchange fixed-size blobs (window IPC handles, pids,
+// devices).  Single node only, so a star around the id's creator is enough: the creator
+// runs a small service thread that gathers one blob per rank and returns the
+// concatenation to everyone.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "rccl_amd.h"
+
+struct RaBootstrap {
+  int fd = -1;
+  int rank = 0, nRanks = 0;
+  // Connect to the endpoint encoded in `id`.  Blocks until all nRanks have joined.
+  ncclResult_t connect(const ncclUniqueId& id, int rank_, int nRanks_);
+  // all[r*bytes .. (r+1)*bytes) = rank r's `mine`.
+  ncclResult_t allGather(const void* mine, void* all, size_t bytes);
+  ncclResult_t barrier();
+  void close();
+};
+
+// Creates the listening endpoint and its service thread, and writes the id.
+ncclResult_t raBootstrapCreate(ncclUniqueId* id);
+// 64-bit value that differs between ids; used to match ranks living in one process.
+uint64_t raBootstrapKey(const ncclUniqueId& id);

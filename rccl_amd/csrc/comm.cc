@@ -1,0 +1,401 @@
+// Communicator lifecycle: windows, peer mappings, device-side tables.
+//
+// Replaces, for one node, the reference's init path (src/init.cc:1188-1874
+// initTransportsRank: peer-info all-gather, transport setup, devCommSetup) and its P2P
+// transport setup/connect (src/transport/p2p.cc:354-561).  There is one transport here —
+// peer-mapped receive windows over xGMI — so "connect" is: allocate one fine-grained
+// window, export it (HIP IPC between processes, plain pointer inside a process), map
+// everybody else's, and hand the table to the kernels.
+#include "comm.h"
+
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <unistd.h>
+
+#include <map>
+
+#include "debug.h"
+#include "topo.h"
+
+namespace {
+
+std::mutex gCliqueMutex;
+std::map<uint64_t, std::weak_ptr<RaClique>> gCliques;
+
+long envLong(const char* name, long def) {
+  const char* e = getenv(name);
+  if (!e || !*e) return def;
+  char* end = nullptr;
+  long v = strtol(e, &end, 0);
+  return end == e ? def : v;
+}
+
+size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct DeviceGuard {
+  int old = -1;
+  DeviceGuard() { if (hipGetDevice(&old) != hipSuccess) old = -1; }
+  ~DeviceGuard() { if (old >= 0) (void)hipSetDevice(old); }
+};
+
+void readTunables(ncclComm* c) {
+  // NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS as in src/graph/connect.cc:521-545; the native
+  // knob is RCCL_AMD_NCHANNELS.
+  long ch = envLong("RCCL_AMD_NCHANNELS", -1);
+  if (ch < 0) ch = envLong("NCCL_MAX_NCHANNELS", 16);
+  long mn = envLong("NCCL_MIN_NCHANNELS", 1);
+  if (ch < mn) ch = mn;
+  if (ch < 1) ch = 1;
+  if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
+  c->maxChannels = (int)ch;
+  long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 512));
+  c->blockThreads = nt <= 256 ? 256 : 512;
+  c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
+  if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
+  c->algoEnv = -1;
+  const char* a = getenv("NCCL_ALGO");    // src/graph/tuning.cc:476-485
+  if (a && *a) {
+    if (!strcasecmp(a, "ring")) c->algoEnv = RA_ALGO_RING;
+    else if (!strcasecmp(a, "tree")) c->algoEnv = RA_ALGO_TREE;
+    else if (!strcasecmp(a, "direct")) c->algoEnv = RA_ALGO_DIRECT;
+    else RA_WARN("NCCL_ALGO=%s is not one of Ring, Tree, Direct: ignored", a);
+  }
+}
+
+void makeLayout(ncclComm* c) {
+  RaWindowLayout& l = c->lay;
+  l.nRanks = c->nRanks;
+  l.nChannels = c->maxChannels;
+  long slots = envLong("RCCL_AMD_NSLOTS", 4);
+  if (slots < 2) slots = 2;
+  if (slots > 16) slots = 16;
+  l.nSlots = (int)slots;
+  long slotBytes = envLong("RCCL_AMD_SLOT_BYTES", -1);
+  if (slotBytes <= 0) {
+    long buff = envLong("NCCL_BUFFSIZE", -1);      // whole FIFO, as in src/init.cc:837-875
+    slotBytes = buff > 0 ? buff / slots : (512 << 10);
+  }
+  if (slotBytes < 4096) slotBytes = 4096;
+  l.slotBytes = (uint32_t)alignUp((size_t)slotBytes, 4096);
+  l.dataOffset = alignUp(raFlagBytes(l), 4096);
+  l.totalBytes = raDataOffset(l, l.nChannels, 0, 0);   // one past the last FIFO
+}
+
+ncclResult_t allocWindow(ncclComm* c) {
+  makeLayout(c);
+  if (c->nRanks == 1) return ncclSuccess;
+  const char* kind = getenv("RCCL_AMD_WINDOW_MEM");
+  void* p = nullptr;
+  hipError_t e = hipErrorUnknown;
+  // Same preference as the reference's FIFO allocation: uncached, else fine-grained
+  // (src/include/alloc.h:34-36, src/transport/p2p.cc:231-235).
+  if (!kind || !strcasecmp(kind, "uncached")) e = hipExtMallocWithFlags(&p, c->lay.totalBytes, hipDeviceMallocUncached);
+  if (e != hipSuccess && (!kind || strcasecmp(kind, "coarse")))
+    e = hipExtMallocWithFlags(&p, c->lay.totalBytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) e = hipMalloc(&p, c->lay.totalBytes);
+  if (e != hipSuccess) {
+    RA_WARN("cannot allocate the %zu-byte receive window: %s", c->lay.totalBytes, hipGetErrorString(e));
+    return ncclUnhandledCudaError;
+  }
+  (void)hipGetLastError();
+  c->window = (char*)p;
+  RA_HIP(hipMemset(p, 0, c->lay.dataOffset));   // all flag words start at zero
+  RA_HIP(hipDeviceSynchronize());
+  RA_INFO("rank %d: window %p, %zu MiB (%d channels x %d ranks x %d kinds x %d slots x %u KiB)", c->rank, p,
+          c->lay.totalBytes >> 20, c->lay.nChannels, c->nRanks, RA_NKINDS, c->lay.nSlots, c->lay.slotBytes >> 10);
+  return ncclSuccess;
+}
+
+void computeRings(ncclComm* c) {
+  const int n = c->nRanks;
+  std::vector<int> adj((size_t)n * n, 1);
+  for (int i = 0; i < n; i++) adj[(size_t)i * n + i] = 0;
+  std::vector<std::vector<int>> rings;
+  raTopoRings(n, adj.data(), RA_MAX_CHANNELS, rings);
+  if (rings.empty()) {
+    std::vector<int> r;
+    for (int i = 0; i < n; i++) r.push_back(i);
+    rings.push_back(r);
+  }
+  c->nRings = (int)rings.size();
+  for (int r = 0; r < c->nRings; r++)
+    for (int i = 0; i < n; i++) c->ringRanks[r][i] = (int8_t)rings[(size_t)r][(size_t)i];
+}
+
+ncclResult_t buildDevComm(ncclComm* c) {
+  const size_t nSteps = (size_t)c->lay.nChannels * c->nRanks * RA_NKINDS;
+  RA_HIP(hipMalloc((void**)&c->steps, 2 * nSteps * sizeof(uint64_t)));
+  RA_HIP(hipMemset(c->steps, 0, 2 * nSteps * sizeof(uint64_t)));
+  RA_HIP(hipHostMalloc((void**)&c->hostFlags, 64, hipHostMallocMapped));
+  memset(c->hostFlags, 0, 64);
+  RA_HIP(hipHostGetDevicePointer((void**)&c->hostFlagsDev, c->hostFlags, 0));
+  RA_HIP(hipEventCreateWithFlags(&c->orderEvent, hipEventDisableTiming));
+  computeRings(c);
+
+  RaDevComm h;
+  memset(&h, 0, sizeof h);
+  h.rank = c->rank;
+  h.nRanks = c->nRanks;
+  h.lay = c->lay;
+  for (int p = 0; p < c->nRanks; p++) h.win[p] = c->peerWin[p];
+  h.sendStep = c->steps;
+  h.recvStep = c->steps + nSteps;
+  h.abortFlag = c->hostFlagsDev;
+  h.errorFlag = c->hostFlagsDev + 1;
+  // wall_clock64() ticks at 100 MHz on gfx950
+  long ms = envLong("RCCL_AMD_SPIN_TIMEOUT_MS", 120000);
+  if (ms < 1) ms = 1;
+  h.timeoutTicks = (uint64_t)ms * 100000ull;
+  h.nRings = c->nRings;
+  memcpy(h.ringRanks, c->ringRanks, sizeof h.ringRanks);
+  RA_HIP(hipMalloc((void**)&c->devComm, sizeof h));
+  RA_HIP(hipMemcpy(c->devComm, &h, sizeof h, hipMemcpyHostToDevice));
+  RA_HIP(hipDeviceSynchronize());
+  return ncclSuccess;
+}
+
+ncclResult_t enablePeer(int myDev, int peerDev) {
+  if (myDev == peerDev) return ncclSuccess;
+  int can = 0;
+  RA_HIP(hipDeviceCanAccessPeer(&can, myDev, peerDev));
+  if (!can) {
+    RA_WARN("device %d cannot access device %d peer-to-peer", myDev, peerDev);
+    return ncclSystemError;
+  }
+  hipError_t e = hipDeviceEnablePeerAccess(peerDev, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+    RA_WARN("hipDeviceEnablePeerAccess(%d) from %d: %s", peerDev, myDev, hipGetErrorString(e));
+    return ncclUnhandledCudaError;
+  }
+  (void)hipGetLastError();
+  return ncclSuccess;
+}
+
+void freeLocal(ncclComm* c) {
+  if (c->devComm) (void)hipFree(c->devComm);
+  if (c->steps) (void)hipFree(c->steps);
+  if (c->hostFlags) (void)hipHostFree(c->hostFlags);
+  if (c->orderEvent) (void)hipEventDestroy(c->orderEvent);
+  c->devComm = nullptr; c->steps = nullptr; c->hostFlags = nullptr; c->orderEvent = nullptr;
+}
+
+}  // namespace
+
+RaClique::~RaClique() {
+  DeviceGuard g;
+  for (size_t r = 0; r < window.size(); r++)
+    if (window[r]) {
+      (void)hipSetDevice(device[r]);
+      (void)hipFree(window[r]);
+    }
+}
+
+ncclResult_t raCommCheck(const ncclComm* comm, const char* what) {
+  // src/misc/argcheck.cc:36-43
+  if (comm == nullptr) { RA_WARN("%s: communicator is NULL", what); return ncclInvalidArgument; }
+  if (comm->magic != RA_COMM_MAGIC) { RA_WARN("%s: communicator is corrupted or already destroyed", what); return ncclInvalidArgument; }
+  return ncclSuccess;
+}
+
+ncclResult_t raCommPollError(ncclComm* c) {
+  if (c->asyncError == ncclSuccess && c->hostFlags) {
+    const uint32_t e = __atomic_load_n(&c->hostFlags[1], __ATOMIC_RELAXED);
+    if (e == RA_ERR_TIMEOUT) {
+      c->asyncError = ncclRemoteError;
+      RA_WARN("rank %d: a device-side wait for a peer timed out; the communicator is unusable", c->rank);
+    } else if (e == RA_ERR_ABORTED) {
+      c->asyncError = ncclInternalError;
+    }
+  }
+  return c->asyncError;
+}
+
+ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
+  // src/init.cc:2365-2420
+  if (!comms || ndev < 1) { RA_WARN("ncclCommInitAll: invalid arguments"); return ncclInvalidArgument; }
+  if (ndev > RA_MAX_RANKS) { RA_WARN("ncclCommInitAll: at most %d ranks per node", RA_MAX_RANKS); return ncclInvalidArgument; }
+  int ngpu = 0;
+  RA_HIP(hipGetDeviceCount(&ngpu));
+  std::vector<int> devs((size_t)ndev);
+  const bool allowDup = envLong("RCCL_AMD_MULTI_RANK_GPU", 0) != 0;
+  for (int i = 0; i < ndev; i++) {
+    devs[(size_t)i] = devlist ? devlist[i] : i;
+    if (devs[(size_t)i] < 0 || devs[(size_t)i] >= ngpu) { RA_WARN("ncclCommInitAll: invalid device %d", devs[(size_t)i]); return ncclInvalidArgument; }
+    for (int j = 0; j < i; j++)
+      if (devs[(size_t)j] == devs[(size_t)i] && !allowDup) {
+        RA_WARN("ncclCommInitAll: device %d is listed twice (set RCCL_AMD_MULTI_RANK_GPU=1 to allow it)", devs[(size_t)i]);
+        return ncclInvalidArgument;
+      }
+  }
+  DeviceGuard guard;
+  auto clique = std::make_shared<RaClique>();
+  clique->nRanks = ndev;
+  clique->window.assign((size_t)ndev, nullptr);
+  clique->device = devs;
+  std::vector<ncclComm*> cs((size_t)ndev, nullptr);
+  ncclResult_t res = ncclSuccess;
+  for (int i = 0; i < ndev && res == ncclSuccess; i++) {
+    ncclComm* c = new ncclComm;
+    cs[(size_t)i] = c;
+    c->rank = i; c->nRanks = ndev; c->device = devs[(size_t)i]; c->clique = clique;
+    readTunables(c);
+    if (hipSetDevice(c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+    res = allocWindow(c);
+    clique->window[(size_t)i] = c->window;
+  }
+  for (int i = 0; i < ndev && res == ncclSuccess; i++) {
+    ncclComm* c = cs[(size_t)i];
+    if (hipSetDevice(c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+    for (int j = 0; j < ndev && res == ncclSuccess; j++) {
+      c->peerWin[j] = cs[(size_t)j]->window;
+      res = enablePeer(c->device, cs[(size_t)j]->device);
+    }
+    if (res == ncclSuccess) res = buildDevComm(c);
+  }
+  if (res != ncclSuccess) {
+    for (ncclComm* c : cs) if (c) { freeLocal(c); c->magic = 0; delete c; }
+    return res;
+  }
+  clique->joined = ndev;
+  for (int i = 0; i < ndev; i++) comms[i] = cs[(size_t)i];
+  return ncclSuccess;
+}
+
+namespace {
+struct PeerInfo {            // one per rank, all-gathered at init (cf. src/include/transport.h:36-50)
+  int32_t rank, pid, device, maxChannels;
+  uint32_t slotBytes; int32_t nSlots;
+  uint64_t hostHash;
+  uint64_t windowPtr;        // meaningful inside the owner's process only
+  hipIpcMemHandle_t handle;
+  int32_t haveHandle, pad;
+};
+uint64_t hostHash() {
+  char name[256] = "";
+  (void)gethostname(name, sizeof name - 1);
+  uint64_t h = 1469598103934665603ull;
+  for (const char* p = name; *p; p++) h = (h ^ (uint64_t)(unsigned char)*p) * 1099511628211ull;
+  return h;
+}
+}  // namespace
+
+ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config) {
+  // src/init.cc:2281-2346 (argument checks), 1188-1874 (transport setup)
+  if (!out) { RA_WARN("ncclCommInitRank: comm is NULL"); return ncclInvalidArgument; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { RA_WARN("ncclCommInitRank: invalid rank %d of %d", rank, nranks); return ncclInvalidArgument; }
+  if (nranks > RA_MAX_RANKS) { RA_WARN("ncclCommInitRank: at most %d ranks per node", RA_MAX_RANKS); return ncclInvalidArgument; }
+  if (config && (config->magic != 0xcafebeef || config->size < sizeof(size_t) + 2 * sizeof(unsigned))) {
+    RA_WARN("ncclCommInitRankConfig: config was not initialised with NCCL_CONFIG_INITIALIZER");
+    return ncclInvalidArgument;
+  }
+  ncclComm* c = new ncclComm;
+  c->rank = rank; c->nRanks = nranks;
+  if (config && config->blocking != NCCL_CONFIG_UNDEF_INT) c->blocking = config->blocking != 0;
+  ncclResult_t res = ncclSuccess;
+  std::vector<PeerInfo> all((size_t)nranks);
+  PeerInfo me;
+  const uint64_t key = raBootstrapKey(id);
+  do {
+    if (hipGetDevice(&c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+    readTunables(c);
+    if (nranks == 1) {
+      makeLayout(c);
+      c->clique = std::make_shared<RaClique>();
+      res = buildDevComm(c);
+      break;
+    }
+    c->multiProcess = true;
+    if ((res = c->boot.connect(id, rank, nranks)) != ncclSuccess) break;
+    if ((res = allocWindow(c)) != ncclSuccess) break;
+    memset(&me, 0, sizeof me);
+    me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
+    me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash();
+    me.windowPtr = (uint64_t)(uintptr_t)c->window;
+    me.haveHandle = hipIpcGetMemHandle(&me.handle, c->window) == hipSuccess;
+    (void)hipGetLastError();
+    if ((res = c->boot.allGather(&me, all.data(), sizeof me)) != ncclSuccess) break;
+
+    // Same-process ranks share a clique that owns their windows.
+    {
+      std::lock_guard<std::mutex> g(gCliqueMutex);
+      auto it = gCliques.find(key);
+      if (it != gCliques.end()) c->clique = it->second.lock();
+      if (!c->clique) {
+        c->clique = std::make_shared<RaClique>();
+        c->clique->key = key; c->clique->nRanks = nranks;
+        c->clique->window.assign((size_t)nranks, nullptr);
+        c->clique->device.assign((size_t)nranks, 0);
+        gCliques[key] = c->clique;
+      }
+      c->clique->window[(size_t)rank] = c->window;
+      c->clique->device[(size_t)rank] = c->device;
+      c->clique->joined++;
+    }
+    for (int p = 0; p < nranks && res == ncclSuccess; p++) {
+      const PeerInfo& pi = all[(size_t)p];
+      if (pi.hostHash != me.hostHash) { RA_WARN("rank %d is on another host: only one node is supported", p); res = ncclInvalidUsage; break; }
+      if (pi.maxChannels != me.maxChannels || pi.slotBytes != me.slotBytes || pi.nSlots != me.nSlots) {
+        RA_WARN("rank %d uses different channel/slot settings (%d ch, %u B, %d slots) than rank %d (%d, %u, %d)", p,
+                pi.maxChannels, pi.slotBytes, pi.nSlots, rank, me.maxChannels, me.slotBytes, me.nSlots);
+        res = ncclInvalidUsage; break;
+      }
+      if (p == rank) { c->peerWin[p] = c->window; continue; }
+      if (pi.pid == me.pid) {
+        c->peerWin[p] = (char*)(uintptr_t)pi.windowPtr;
+        res = enablePeer(c->device, pi.device);
+      } else {
+        if (!pi.haveHandle) { RA_WARN("rank %d could not export its window (hipIpcGetMemHandle failed)", p); res = ncclSystemError; break; }
+        void* mapped = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&mapped, pi.handle, hipIpcMemLazyEnablePeerAccess);   // src/transport/p2p.cc:292
+        if (e != hipSuccess) { RA_WARN("hipIpcOpenMemHandle for rank %d's window: %s", p, hipGetErrorString(e)); res = ncclUnhandledCudaError; break; }
+        c->peerWin[p] = (char*)mapped;
+        c->peerIsIpc[p] = true;
+      }
+    }
+    if (res != ncclSuccess) break;
+    if ((res = buildDevComm(c)) != ncclSuccess) break;
+    res = c->boot.barrier();      // nobody launches before every window is mapped everywhere
+  } while (0);
+  if (res != ncclSuccess) {
+    RA_WARN("ncclCommInitRank failed for rank %d of %d", rank, nranks);
+    c->boot.close();
+    for (int p = 0; p < nranks; p++) if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
+    freeLocal(c);
+    c->magic = 0;
+    delete c;
+    return res;
+  }
+  *out = c;
+  return ncclSuccess;
+}
+
+ncclResult_t raCommDestroy(ncclComm_t c, bool abort) {
+  RA_CHECK(raCommCheck(c, abort ? "ncclCommAbort" : "ncclCommDestroy"));
+  DeviceGuard guard;
+  (void)hipSetDevice(c->device);
+  if (abort && c->hostFlags) __atomic_store_n(&c->hostFlags[0], 1u, __ATOMIC_RELAXED);   // spins give up
+  // Everything this rank enqueued must have left the GPU before the tables go away.
+  if (c->haveLast) (void)hipStreamSynchronize(c->lastStream);
+  (void)hipGetLastError();
+  if (c->multiProcess) {
+    // Peers may still be posting credits into this window: leave together.
+    if (!abort) (void)c->boot.barrier();
+    c->boot.close();
+    for (int p = 0; p < c->nRanks; p++)
+      if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
+  }
+  freeLocal(c);
+  {
+    std::lock_guard<std::mutex> g(gCliqueMutex);
+    if (c->clique && c->clique->key) {
+      c->clique->left++;
+      if (c->clique->left >= c->clique->joined) gCliques.erase(c->clique->key);
+    }
+    c->clique.reset();     // the last sibling frees the windows
+  }
+  c->magic = 0;
+  delete c;
+  return ncclSuccess;
+}

@@ -1,0 +1,101 @@
+// Host-side communicator state.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "bootstrap.h"
+#include "device_types.h"
+#include "rccl_amd.h"
+
+#define RA_COMM_MAGIC 0x52434d4d414d4431ull
+#define RA_MAX_USER_OPS 64
+
+// Ranks of one communicator that live in the same process reach each other's windows by
+// plain pointers (the reference's same-process P2P path, src/transport/p2p.cc:318-344).
+// The clique owns those windows so that none is freed while a sibling may still write it.
+struct RaClique {
+  std::mutex m;
+  uint64_t key = 0;
+  int nRanks = 0;
+  int joined = 0, left = 0;
+  std::vector<char*> window;   // per rank, null for ranks of other processes
+  std::vector<int> device;
+  ~RaClique();
+};
+
+struct RaUserOp {
+  bool used = false;
+  int dtype = 0;
+  uint64_t arg = 0;          // scalar bits (host-immediate)
+  const void* argPtr = nullptr;  // device-resident scalar
+};
+
+struct ncclComm {
+  uint64_t magic = RA_COMM_MAGIC;
+  int rank = 0, nRanks = 1, device = 0;
+  bool blocking = true;
+
+  // tunables (environment, read once at init)
+  int maxChannels = 16;
+  int blockThreads = 512;
+  int algoEnv = -1;          // NCCL_ALGO: -1 unset
+  size_t minChunkBytes = 32 << 10;
+
+  // device resources
+  RaWindowLayout lay{};
+  char* window = nullptr;            // my window (owned by the clique)
+  char* peerWin[RA_MAX_RANKS] = {};
+  bool peerIsIpc[RA_MAX_RANKS] = {};
+  RaDevComm* devComm = nullptr;
+  uint64_t* steps = nullptr;         // sendStep + recvStep
+  uint32_t* hostFlags = nullptr;     // pinned, mapped: [0] abort request, [1] device error
+  uint32_t* hostFlagsDev = nullptr;
+  int nRings = 0;
+  int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
+
+  std::shared_ptr<RaClique> clique;
+  RaBootstrap boot;
+  bool multiProcess = false;
+
+  // launch ordering between user streams
+  hipStream_t lastStream = nullptr;
+  bool haveLast = false;
+  hipEvent_t orderEvent = nullptr;
+
+  ncclResult_t asyncError = ncclSuccess;
+  RaUserOp userOps[RA_MAX_USER_OPS];
+  bool finalized = false;
+};
+
+// comm.cc
+ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t raCommInitRank(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config);
+ncclResult_t raCommDestroy(ncclComm_t comm, bool abort);
+ncclResult_t raCommCheck(const ncclComm* comm, const char* what);
+ncclResult_t raCommPollError(ncclComm* comm);
+
+// enqueue.cc
+struct RaPlan {
+  int algo, proto, nChannels, grid, block;
+  size_t chunkElems, lastChunkElems;
+};
+struct RaCollArgs {
+  int coll;
+  const void* send;
+  void* recv;
+  size_t count;
+  int dtype;
+  int op;                    // ncclRedOp_t value (may be a user op handle)
+  ncclComm* comm;
+  hipStream_t stream;
+};
+ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
+ncclResult_t raEnqueue(const RaCollArgs& a);
+ncclResult_t raGroupStart();
+ncclResult_t raGroupEnd();
+int raGroupDepth();
+void raGroupAddInit(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config, int device);
+size_t raTypeSize(int dtype);

@@ -1,0 +1,87 @@
+// Structures shared by the host planner and the HIP kernels.
+//
+// Vocabulary
+//   window   : one fine-grained device allocation per rank that every peer maps
+//              (HIP IPC or direct pointer).  It holds that rank's receive FIFOs and all
+//              flag words other ranks write.  Role of the reference's per-connection
+//              ncclRecvMem/ncclSendMem + SIMPLE buffers (src/include/comm.h:44-68,
+//              src/transport/p2p.cc:212-246,490-561), folded into one region.
+//   channel  : an independent slice of the work driven by its own workgroups
+//              (reference: one workgroup per channel, src/device/common.h:230-379).
+//   conn     : FIFO (channel, sender, receiver, kind).  Slots live in the receiver's
+//              window; `tail` (slots published) sits beside them and is written by the
+//              sender; `head` (slots consumed) sits in the SENDER's window and is written
+//              by the receiver.  Both ends therefore poll local memory only
+//              (reference protocol: src/device/prims_simple.h:111-182).
+//   kind     : 0 = reduce phase traffic (scatter / ring / tree-up),
+//              1 = broadcast phase traffic (gather / tree-down).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define RA_MAX_RANKS 16
+#define RA_MAX_CHANNELS 64
+#define RA_NKINDS 2
+#define RA_FLAG_STRIDE 128  // bytes between two flag words: one writer per line
+#define RA_MAX_SRCS 8   // sources / destinations of one reduce-copy
+
+// collectives
+enum { RA_COLL_ALLREDUCE = 0, RA_COLL_REDUCESCATTER = 1, RA_COLL_ALLGATHER = 2 };
+// algorithms
+enum { RA_ALGO_DIRECT = 0, RA_ALGO_RING = 1, RA_ALGO_TREE = 2 };
+// device reduction ops (reference ncclDevRedOp_t, src/include/device.h; built by
+// hostToDevRedOp, src/enqueue.cc:1962-2057)
+enum { RA_OP_SUM = 0, RA_OP_PROD = 1, RA_OP_MAX = 2, RA_OP_MIN = 3, RA_OP_PREMULSUM = 4, RA_OP_SUMPOSTDIV = 5,
+       RA_NUM_OPS = 6 };
+// device error codes written to RaDevComm::errorFlag
+enum { RA_ERR_NONE = 0, RA_ERR_TIMEOUT = 1, RA_ERR_ABORTED = 2 };
+
+struct RaWindowLayout {
+  int nRanks;
+  int nChannels;      // channels the window has room for
+  int nSlots;         // FIFO depth (reference NCCL_STEPS = 8, src/include/device.h:32)
+  uint32_t slotBytes; // bytes per slot (reference step size 512 KiB, src/init.cc:839)
+  size_t dataOffset;  // start of the slot storage inside the window
+  size_t totalBytes;
+};
+
+// Flag word index -> byte offset.  which: 0 = tail (written by the sender `peer`),
+// 1 = head (written by the receiver `peer`).
+__host__ __device__ inline size_t raFlagOffset(const RaWindowLayout& l, int which, int ch, int peer, int kind) {
+  return ((((size_t)which * l.nChannels + ch) * l.nRanks + peer) * RA_NKINDS + kind) * RA_FLAG_STRIDE;
+}
+__host__ __device__ inline size_t raFlagBytes(const RaWindowLayout& l) {
+  return (size_t)2 * l.nChannels * l.nRanks * RA_NKINDS * RA_FLAG_STRIDE;
+}
+// Slot storage of the FIFO on which `peer` sends to the window's owner.
+__host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, int peer, int kind) {
+  return l.dataOffset + ((((size_t)ch * l.nRanks + peer) * RA_NKINDS + kind) * l.nSlots) * (size_t)l.slotBytes;
+}
+
+struct RaDevComm {
+  int rank;
+  int nRanks;
+  RaWindowLayout lay;
+  char* win[RA_MAX_RANKS];    // win[rank] is local; the others are peer mappings
+  uint64_t* sendStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has published
+  uint64_t* recvStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has consumed
+  uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
+  uint32_t* errorFlag;        // host-mapped; first device error code
+  uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
+  // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
+  int nRings;
+  int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
+};
+
+struct RaWork {
+  int coll;
+  int algo;
+  int nChannels;
+  int elemSize;
+  const char* send;
+  char* recv;
+  size_t count;        // all-reduce: elements; reduce-scatter / all-gather: elements per rank
+  size_t chunkElems;   // elements one owner handles per round (a multiple of 16 bytes)
+  size_t lastChunkElems;  // same, for the final partial round
+  uint64_t opArg;      // PreMulSum scalar bits / SumPostDiv divisor
+};

@@ -1,0 +1,292 @@
+// Argument checks, reduction-op translation, planning and launch.
+//
+// Replaces the reference's enqueue path for the three collectives (src/enqueue.cc:
+// 2182-2217 ncclEnqueueCheck, 2075-2180 taskAppend, 1962-2057 hostToDevRedOp,
+// 1574-1727 algorithm/channel choice, 1844-1913 chunk sizing, 1434-1446 launch) and the
+// group bracket (src/group.cc:96-102,384-448).  One kernel launch per collective per
+// rank; the work descriptor travels as a kernel argument instead of through a work FIFO.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "comm.h"
+#include "debug.h"
+#include "launch.h"
+
+size_t raTypeSize(int dt) {
+  switch (dt) {
+    case ncclInt8: case ncclUint8: case ncclFp8E4M3: case ncclFp8E5M2: return 1;
+    case ncclFloat16: case ncclBfloat16: return 2;
+    case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+    case ncclInt64: case ncclUint64: case ncclFloat64: return 8;
+    default: return 0;
+  }
+}
+
+namespace {
+
+size_t alignUp(size_t x, size_t a) { return (x + a - 1) / a * a; }
+size_t divUp(size_t x, size_t a) { return (x + a - 1) / a; }
+
+struct DeviceGuard {
+  int old = -1;
+  bool changed = false;
+  void set(int dev) {
+    if (hipGetDevice(&old) == hipSuccess && old != dev) { (void)hipSetDevice(dev); changed = true; }
+  }
+  ~DeviceGuard() { if (changed) (void)hipSetDevice(old); }
+};
+
+uint16_t f32ToF16Bits(float f) {   // IEEE binary16, round to nearest even
+  uint32_t x; memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u, mant = x & 0x7fffffu;
+  int32_t exp = (int32_t)((x >> 23) & 0xffu);
+  if (exp == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u | (mant >> 13) : 0u));
+  exp = exp - 127 + 15;
+  if (exp >= 0x1f) return (uint16_t)(sign | 0x7c00u);
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    mant |= 0x800000u;
+    uint32_t shift = (uint32_t)(14 - exp), h = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1u))) h++;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)exp << 10) | (mant >> 13), rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+  return (uint16_t)(sign | h);
+}
+uint16_t f32ToBf16Bits(float f) {  // as hip_bfloat16
+  uint32_t u; memcpy(&u, &f, 4);
+  if (~u & 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+  else if (u & 0xffffu) u |= 0x10000u;
+  return (uint16_t)(u >> 16);
+}
+
+// ncclRedOp_t + datatype -> device op and its scalar (src/enqueue.cc:1962-2057).
+ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, uint64_t* arg, const void** argPtr) {
+  *arg = 0; *argPtr = nullptr;
+  switch (op) {
+    case ncclSum: *devOp = RA_OP_SUM; return ncclSuccess;
+    case ncclProd: *devOp = RA_OP_PROD; return ncclSuccess;
+    case ncclMax: *devOp = RA_OP_MAX; return ncclSuccess;
+    case ncclMin: *devOp = RA_OP_MIN; return ncclSuccess;
+    case ncclAvg: {
+      const int n = comm->nRanks;
+      switch (dtype) {
+        case ncclInt8: case ncclInt32: case ncclInt64: case ncclUint8: case ncclUint32: case ncclUint64:
+          *devOp = RA_OP_SUMPOSTDIV; *arg = (uint64_t)n; return ncclSuccess;
+        case ncclFloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToF16Bits(float(1.0 / n)); return ncclSuccess;
+        case ncclBfloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToBf16Bits(float(1.0 / n)); return ncclSuccess;
+        case ncclFloat32: { float s = float(1.0 / n); uint32_t u; memcpy(&u, &s, 4); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
+        case ncclFloat64: { double s = 1.0 / n; uint64_t u; memcpy(&u, &s, 8); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
+        default: return ncclInvalidArgument;
+      }
+    }
+    default: {
+      const int ix = op - (int)ncclNumOps;
+      if (ix < 0 || ix >= RA_MAX_USER_OPS || !comm->userOps[ix].used) { RA_WARN("invalid reduction operator %d", op); return ncclInvalidArgument; }
+      if (comm->userOps[ix].dtype != dtype) {
+        RA_WARN("Data type supplied to user-created ncclRedOp_t does not match type given to reduction operation");
+        return ncclInvalidArgument;
+      }
+      *devOp = RA_OP_PREMULSUM; *arg = comm->userOps[ix].arg; *argPtr = comm->userOps[ix].argPtr;
+      return ncclSuccess;
+    }
+  }
+}
+
+// ----- group state (thread-local, src/group.cc:19) -------------------------------------------
+struct InitJob {
+  ncclComm_t* out; int nranks; ncclUniqueId id; int rank; ncclConfig_t config; bool haveConfig; int device;
+  ncclResult_t result;
+};
+thread_local int tGroupDepth = 0;
+thread_local std::vector<RaCollArgs> tPending;
+thread_local std::vector<InitJob> tInits;
+thread_local ncclResult_t tGroupError = ncclSuccess;
+
+int gridFor(int coll, int algo, int nCh) {
+  if (algo == RA_ALGO_RING) return nCh;
+  if (algo == RA_ALGO_TREE) return 2 * nCh;
+  return (coll == RA_COLL_ALLREDUCE ? 3 : 2) * nCh;
+}
+
+ncclResult_t launchOne(const RaCollArgs& a) {
+  ncclComm* c = a.comm;
+  const size_t es = raTypeSize(a.dtype);
+  int devOp = RA_OP_SUM; uint64_t arg = 0; const void* argPtr = nullptr;
+  if (a.coll != RA_COLL_ALLGATHER) RA_CHECK(translateOp(c, a.op, a.dtype, &devOp, &arg, &argPtr));
+  DeviceGuard guard;
+  guard.set(c->device);
+  if (argPtr) {
+    // Device-resident scalar (ncclScalarDevice): fetched in stream order, before the kernel.
+    RA_HIP(hipMemcpyAsync(&c->hostFlags[8], argPtr, es, hipMemcpyDeviceToHost, a.stream));
+    RA_HIP(hipStreamSynchronize(a.stream));
+    arg = 0; memcpy(&arg, &c->hostFlags[8], es);
+  }
+  // Operations of one communicator run in issue order even when the streams differ.
+  if (c->haveLast && c->lastStream != a.stream) {
+    RA_HIP(hipEventRecord(c->orderEvent, c->lastStream));
+    RA_HIP(hipStreamWaitEvent(a.stream, c->orderEvent, 0));
+  }
+  c->lastStream = a.stream; c->haveLast = true;
+
+  if (c->nRanks == 1) {
+    // One rank: a copy, or nothing when in place; pre-multiply ops still scale
+    // (src/device/onerank.cu:55-90).
+    const bool scale = (a.coll != RA_COLL_ALLGATHER) && devOp == RA_OP_PREMULSUM;
+    if (a.send == a.recv && !scale) return ncclSuccess;
+    const void* srcs[1] = {a.send};
+    const size_t bytes = a.count * es;
+    int grid = (int)divUp(bytes, 256 * 64);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    hipError_t e = scale ? raLaunchLocal(a.recv, srcs, 1, 0, false, arg, a.count, a.dtype, RA_OP_PREMULSUM, grid, a.stream)
+                         : raLaunchLocal(a.recv, srcs, 1, -1, false, 0, bytes, ncclInt8, RA_OP_SUM, grid, a.stream);
+    if (e != hipSuccess) { RA_WARN("local kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
+    return ncclSuccess;
+  }
+
+  RaPlan p;
+  RA_CHECK(raPlan(c, a.coll, a.count, a.dtype, &p));
+  RaWork w;
+  memset(&w, 0, sizeof w);
+  w.coll = a.coll; w.algo = p.algo; w.nChannels = p.nChannels; w.elemSize = (int)es;
+  w.send = (const char*)a.send; w.recv = (char*)a.recv; w.count = a.count;
+  w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg;
+  RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
+           a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
+  hipError_t e = raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);
+  if (e != hipSuccess) { RA_WARN("collective kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
+  return ncclSuccess;
+}
+
+ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
+  // src/misc/argcheck.cc:45-84
+  RA_CHECK(raCommCheck(a.comm, name));
+  if (a.dtype < 0 || a.dtype >= ncclNumTypes) { RA_WARN("%s: invalid type %d", name, a.dtype); return ncclInvalidArgument; }
+  if (a.coll != RA_COLL_ALLGATHER) {
+    if (a.dtype == ncclFp8E4M3 || a.dtype == ncclFp8E5M2) {
+      RA_WARN("%s: fp8 reductions are not provided by this library", name);
+      return ncclInvalidArgument;
+    }
+    if (a.op < 0 || (a.op >= ncclNumOps && (a.op - ncclNumOps >= RA_MAX_USER_OPS || !a.comm->userOps[a.op - ncclNumOps].used))) {
+      RA_WARN("%s: invalid reduction operation %d", name, a.op);
+      return ncclInvalidArgument;
+    }
+  }
+  if (a.count == 0) return ncclSuccess;
+  if (a.send == nullptr || a.recv == nullptr) { RA_WARN("%s: sendbuff/recvbuff is NULL", name); return ncclInvalidArgument; }
+  return ncclSuccess;
+}
+
+}  // namespace
+
+// Plan: algorithm, channels and chunk.  The reference prices (algorithm, protocol) pairs
+// with an analytic model tuned for older parts (src/graph/tuning.cc:368-424); here the
+// all-pairs schedule is the default wherever every rank has its own link to every other
+// (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
+// and NCCL_ALGO selects the ring or chain schedules.
+ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
+  const size_t es = raTypeSize(dtype);
+  if (es == 0) return ncclInvalidArgument;
+  const int n = c->nRanks;
+  int algo = c->algoEnv >= 0 ? c->algoEnv : RA_ALGO_DIRECT;
+  if (algo == RA_ALGO_TREE && coll != RA_COLL_ALLREDUCE) algo = RA_ALGO_RING;   // no chain schedule for these two
+  if (algo == RA_ALGO_DIRECT && n > RA_MAX_SRCS) algo = RA_ALGO_RING;
+  p->algo = algo;
+  p->proto = 0;
+  p->block = c->blockThreads;
+  const size_t unit = 16 / es;                                  // elements per 16-byte pack
+  const size_t maxChunk = (size_t)c->lay.slotBytes / es;        // one FIFO slot
+  const size_t minChunk = alignUp(c->minChunkBytes / es, unit);
+  // elements each owner handles in total
+  size_t perOwner;
+  if (coll == RA_COLL_ALLREDUCE && algo != RA_ALGO_TREE) perOwner = divUp(count, (size_t)n);
+  else perOwner = count;
+  // channels: enough that each has at least one minimum chunk
+  size_t nCh = divUp(perOwner, minChunk);
+  if (nCh < 1) nCh = 1;
+  if (nCh > (size_t)c->maxChannels) nCh = (size_t)c->maxChannels;
+  // chunk: about four rounds per channel when the data allows, never above one slot
+  size_t chunk = alignUp(divUp(perOwner, nCh * 4), unit);
+  if (chunk < minChunk) chunk = minChunk;
+  if (chunk > maxChunk) chunk = maxChunk / unit * unit;
+  p->nChannels = (int)nCh;
+  p->chunkElems = chunk;
+  p->lastChunkElems = chunk;
+  if (coll == RA_COLL_ALLREDUCE && algo != RA_ALGO_TREE) {
+    const size_t roundElems = chunk * (size_t)n;
+    const size_t nRounds = divUp(count, roundElems);
+    const size_t rem = count - (nRounds - 1) * roundElems;
+    size_t last = alignUp(divUp(rem, (size_t)n), unit);         // cf. src/enqueue.cc:277-297
+    if (last > chunk) last = chunk;
+    p->lastChunkElems = last;
+  }
+  p->grid = gridFor(coll, algo, p->nChannels);
+  return ncclSuccess;
+}
+
+int raGroupDepth() { return tGroupDepth; }
+
+ncclResult_t raGroupStart() {
+  tGroupDepth++;
+  return ncclSuccess;
+}
+
+void raGroupAddInit(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config, int device) {
+  InitJob j;
+  j.out = comm; j.nranks = nranks; j.id = id; j.rank = rank; j.haveConfig = config != nullptr; j.device = device;
+  if (config) j.config = *config;
+  j.result = ncclSuccess;
+  tInits.push_back(j);
+}
+
+ncclResult_t raGroupEnd() {
+  if (tGroupDepth == 0) { RA_WARN("ncclGroupEnd: not in a group call"); return ncclInvalidUsage; }
+  if (--tGroupDepth > 0) return ncclSuccess;
+  ncclResult_t res = tGroupError;
+  tGroupError = ncclSuccess;
+  // Communicator creation inside a group: every rank's init blocks on the others, so each
+  // runs on its own thread (src/group.cc:311-349).
+  if (!tInits.empty()) {
+    std::vector<InitJob> jobs;
+    jobs.swap(tInits);
+    std::vector<std::thread> th;
+    for (auto& j : jobs)
+      th.emplace_back([&j]() {
+        if (hipSetDevice(j.device) != hipSuccess) { j.result = ncclUnhandledCudaError; return; }
+        j.result = raCommInitRank(j.out, j.nranks, j.id, j.rank, j.haveConfig ? &j.config : nullptr);
+      });
+    for (auto& t : th) t.join();
+    for (auto& j : jobs) if (j.result != ncclSuccess && res == ncclSuccess) res = j.result;
+  }
+  std::vector<RaCollArgs> ops;
+  ops.swap(tPending);
+  if (res != ncclSuccess) return res;   // an error inside the group cancels its launches
+  for (const auto& a : ops) {
+    ncclResult_t r = launchOne(a);
+    if (r != ncclSuccess && res == ncclSuccess) res = r;
+  }
+  return res;
+}
+
+ncclResult_t raEnqueue(const RaCollArgs& a) {
+  static const char* names[] = {"AllReduce", "ReduceScatter", "AllGather"};
+  ncclResult_t r = checkArgs(a, names[a.coll]);
+  if (r == ncclSuccess && a.comm) {
+    r = raCommPollError(a.comm);
+    if (r != ncclSuccess) RA_WARN("%s: the communicator has a pending asynchronous error", names[a.coll]);
+  }
+  if (r != ncclSuccess) {
+    if (tGroupDepth > 0 && tGroupError == ncclSuccess) tGroupError = r;
+    return r;
+  }
+  if (a.count == 0) return ncclSuccess;           // src/enqueue.cc:2078
+  RA_INFO("%s: rank %d sendbuff %p recvbuff %p count %zu datatype %d op %d stream %p", names[a.coll], a.comm->rank,
+          a.send, a.recv, a.count, a.dtype, a.op, (void*)a.stream);
+  if (tGroupDepth > 0) { tPending.push_back(a); return ncclSuccess; }
+  return launchOne(a);
+}

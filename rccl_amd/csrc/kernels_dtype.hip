@@ -1,0 +1,74 @@
+// One translation unit per element type: compiled ten times with -DRA_DTYPE=0..9 (the
+// ncclDataType_t value) so that the builds run in parallel.  Holds the collective kernel
+// and the local reduce-copy kernel for every reduction op of that type.
+#include "kernels_impl.h"
+
+#ifndef RA_DTYPE
+#error "compile with -DRA_DTYPE=<ncclDataType_t value 0..9>"
+#endif
+
+#if RA_DTYPE == 0
+typedef int8_t elem_t;
+#elif RA_DTYPE == 1
+typedef uint8_t elem_t;
+#elif RA_DTYPE == 2
+typedef int32_t elem_t;
+#elif RA_DTYPE == 3
+typedef uint32_t elem_t;
+#elif RA_DTYPE == 4
+typedef int64_t elem_t;
+#elif RA_DTYPE == 5
+typedef uint64_t elem_t;
+#elif RA_DTYPE == 6
+typedef f16_t elem_t;
+#elif RA_DTYPE == 7
+typedef float elem_t;
+#elif RA_DTYPE == 8
+typedef double elem_t;
+#elif RA_DTYPE == 9
+typedef bf16_t elem_t;
+#endif
+#define RA_IS_INT (RA_DTYPE <= 5)
+
+#define RA_CAT2(a, b) a##b
+#define RA_CAT(a, b) RA_CAT2(a, b)
+
+template <int OP>
+static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int block, hipStream_t s) {
+  hipLaunchKernelGGL((raCollKernel<elem_t, OP>), dim3(grid), dim3(block), 0, s, comm, w);
+  return hipGetLastError();
+}
+template <int OP>
+static hipError_t localOp(const RcArgs& a, size_t nelem, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(256), 0, s, a, nelem);
+  return hipGetLastError();
+}
+
+hipError_t RA_CAT(raLaunchCollDt, RA_DTYPE)(const RaDevComm* comm, const RaWork& w, int op, int grid, int block,
+                                            hipStream_t s) {
+  switch (op) {
+    case RA_OP_SUM: return collOp<RA_OP_SUM>(comm, w, grid, block, s);
+    case RA_OP_PROD: return collOp<RA_OP_PROD>(comm, w, grid, block, s);
+    case RA_OP_MAX: return collOp<RA_OP_MAX>(comm, w, grid, block, s);
+    case RA_OP_MIN: return collOp<RA_OP_MIN>(comm, w, grid, block, s);
+    case RA_OP_PREMULSUM: return collOp<RA_OP_PREMULSUM>(comm, w, grid, block, s);
+#if RA_IS_INT
+    case RA_OP_SUMPOSTDIV: return collOp<RA_OP_SUMPOSTDIV>(comm, w, grid, block, s);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t RA_CAT(raLaunchLocalDt, RA_DTYPE)(const RcArgs& a, size_t nelem, int op, int grid, hipStream_t s) {
+  switch (op) {
+    case RA_OP_SUM: return localOp<RA_OP_SUM>(a, nelem, grid, s);
+    case RA_OP_PROD: return localOp<RA_OP_PROD>(a, nelem, grid, s);
+    case RA_OP_MAX: return localOp<RA_OP_MAX>(a, nelem, grid, s);
+    case RA_OP_MIN: return localOp<RA_OP_MIN>(a, nelem, grid, s);
+    case RA_OP_PREMULSUM: return localOp<RA_OP_PREMULSUM>(a, nelem, grid, s);
+#if RA_IS_INT
+    case RA_OP_SUMPOSTDIV: return localOp<RA_OP_SUMPOSTDIV>(a, nelem, grid, s);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -1,0 +1,803 @@
+// HIP kernels for gfx950 (MI355X): the reduce-copy core, the step/credit FIFO
+// protocol between GPUs, and the collective schedules built from them.
+//
+// What this file replaces in the reference (ROCm/rccl):
+//   reduceCopy / reduceCopyPacks            src/device/common_kernel.h:30-265
+//   element ops, pre/post ops               src/device/reduce_kernel.h:44-573
+//   Primitives<ProtoSimple> wait/post/op    src/device/prims_simple.h:111-381
+//   ring / chain schedules                  src/device/all_reduce.h:17-356,
+//                                           reduce_scatter.h:13-58, all_gather.h:13-152
+//   one-rank path                           src/device/onerank.cu:21-90
+// The all-pairs ("direct") schedule has no counterpart there: it is the native
+// schedule for a node whose GPUs are all joined by their own xGMI link.
+//
+// Element-wise, bandwidth-bound work: 16-byte nontemporal accesses, no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+#include "launch.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ element types
+struct bf16_t { uint16_t v; };
+typedef _Float16 f16_t;
+
+// bf16 <-> f32 exactly as hip_bfloat16 does it (round to nearest even, NaN stays NaN),
+// the arithmetic the reference uses for bf16 (reduce_kernel.h:260-262).
+__device__ __forceinline__ float bf2f(bf16_t a) { return __uint_as_float((uint32_t)a.v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if (~u & 0x7f800000u) u += 0x7fffu + ((u >> 16) & 1u);
+  else if (u & 0xffffu) u |= 0x10000u;
+  bf16_t r; r.v = (uint16_t)(u >> 16); return r;
+}
+
+template <typename T> struct IsInt { static constexpr bool value = true; };
+template <> struct IsInt<float> { static constexpr bool value = false; };
+template <> struct IsInt<double> { static constexpr bool value = false; };
+template <> struct IsInt<f16_t> { static constexpr bool value = false; };
+template <> struct IsInt<bf16_t> { static constexpr bool value = false; };
+
+// One binary step of the reduction, in element type T (reduce_kernel.h:163-180,246-272).
+template <typename T, int OP> struct Elem {
+  static __device__ __forceinline__ T red(T a, T b) {
+    if (OP == RA_OP_PROD) return (T)(a * b);
+    if (OP == RA_OP_MAX) return a > b ? a : b;
+    if (OP == RA_OP_MIN) return a < b ? a : b;
+    return (T)(a + b);
+  }
+};
+template <int OP> struct Elem<float, OP> {
+  static __device__ __forceinline__ float red(float a, float b) {
+    if (OP == RA_OP_PROD) return a * b;
+    if (OP == RA_OP_MAX) return fmaxf(a, b);
+    if (OP == RA_OP_MIN) return fminf(a, b);
+    return a + b;
+  }
+};
+template <int OP> struct Elem<double, OP> {
+  static __device__ __forceinline__ double red(double a, double b) {
+    if (OP == RA_OP_PROD) return a * b;
+    if (OP == RA_OP_MAX) return fmax(a, b);
+    if (OP == RA_OP_MIN) return fmin(a, b);
+    return a + b;
+  }
+};
+template <int OP> struct Elem<f16_t, OP> {
+  static __device__ __forceinline__ f16_t red(f16_t a, f16_t b) {
+    if (OP == RA_OP_PROD) return a * b;  // native f16 ops: one rounding, as the reference's half ops
+    if (OP == RA_OP_MAX) return (f16_t)fmaxf((float)a, (float)b);
+    if (OP == RA_OP_MIN) return (f16_t)fminf((float)a, (float)b);
+    return a + b;
+  }
+};
+template <int OP> struct Elem<bf16_t, OP> {
+  static __device__ __forceinline__ bf16_t red(bf16_t a, bf16_t b) {
+    return f2bf(Elem<float, OP>::red(bf2f(a), bf2f(b)));
+  }
+};
+
+// Pre-multiply (FuncPreMulSum, reduce_kernel.h:364-531) and post-divide
+// (FuncSumPostDiv, reduce_kernel.h:546-573).  `arg` carries the scalar's bits.
+template <typename T> __device__ __forceinline__ T argAs(uint64_t arg) {
+  union { uint64_t u; T t; } x; x.u = arg; return x.t;
+}
+template <typename T> struct Scale {
+  static __device__ __forceinline__ T pre(T a, uint64_t arg) { return (T)(a * argAs<T>(arg)); }
+  static __device__ __forceinline__ T post(T a, uint64_t arg) { return (T)(a / (int)arg); }
+};
+template <> struct Scale<bf16_t> {
+  static __device__ __forceinline__ bf16_t pre(bf16_t a, uint64_t arg) { return f2bf(bf2f(a) * bf2f(argAs<bf16_t>(arg))); }
+  static __device__ __forceinline__ bf16_t post(bf16_t a, uint64_t) { return a; }
+};
+template <> struct Scale<f16_t> {
+  static __device__ __forceinline__ f16_t pre(f16_t a, uint64_t arg) { return a * argAs<f16_t>(arg); }
+  static __device__ __forceinline__ f16_t post(f16_t a, uint64_t) { return a; }
+};
+template <> struct Scale<float> {
+  static __device__ __forceinline__ float pre(float a, uint64_t arg) { return a * argAs<float>(arg); }
+  static __device__ __forceinline__ float post(float a, uint64_t) { return a; }
+};
+template <> struct Scale<double> {
+  static __device__ __forceinline__ double pre(double a, uint64_t arg) { return a * argAs<double>(arg); }
+  static __device__ __forceinline__ double post(double a, uint64_t) { return a; }
+};
+
+// ------------------------------------------------------------------ 16-byte packs
+template <typename T> union Pack {
+  u32x4 v;
+  T e[16 / sizeof(T)];
+};
+template <typename T, int OP> __device__ __forceinline__ u32x4 packRed(u32x4 a, u32x4 b) {
+  constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+  Pack<T> x, y; x.v = a; y.v = b;
+#pragma unroll
+  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Elem<T, R>::red(x.e[i], y.e[i]);
+  return x.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 packPre(u32x4 a, uint64_t arg) {
+  Pack<T> x; x.v = a;
+#pragma unroll
+  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::pre(x.e[i], arg);
+  return x.v;
+}
+template <typename T> __device__ __forceinline__ u32x4 packPost(u32x4 a, uint64_t arg) {
+  Pack<T> x; x.v = a;
+#pragma unroll
+  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::post(x.e[i], arg);
+  return x.v;
+}
+
+__device__ __forceinline__ u32x4 ldPack(const u32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stPack(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+
+// ------------------------------------------------------------------ reduce-copy
+// dst[k][i] = post( pre?(src[0][i]) (op) src[1][i] (op) ... ), folded left to right.
+// `preIdx` is the one source that gets the pre-multiply (this rank's own input; the
+// others arrive already scaled), or -1.
+struct RcArgs {
+  const char* src[RA_MAX_SRCS];
+  char* dst[RA_MAX_SRCS];
+  int ns, nd, preIdx;
+  bool post;
+  uint64_t opArg;
+};
+
+// Packs [first, npacks) in tiles of nthr*U packs; tile t starts at first + t*tileStep.
+// NS > 0: the source count is a compile-time constant and all NS*U loads are issued
+// before the first use, so one wave keeps NS*U KiB in flight.  NS == 0: any count.
+template <typename T, int OP, int NS, int U>
+__device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacks, size_t first, size_t tileStep, int tid, int nthr) {
+  constexpr int NSA = NS > 0 ? NS : 1;
+  const u32x4* s[NSA];
+#pragma unroll
+  for (int j = 0; j < NSA; j++) s[j] = (const u32x4*)a.src[j];
+  const size_t tile = (size_t)nthr * U;
+  size_t base = first;
+  for (; base + tile <= npacks; base += tileStep) {
+    const size_t i0 = base + tid;
+    u32x4 acc[U];
+    if (NS > 0) {
+      u32x4 v[NSA][U];
+#pragma unroll
+      for (int j = 0; j < NSA; j++)
+#pragma unroll
+        for (int u = 0; u < U; u++) v[j][u] = ldPack(s[j] + i0 + (size_t)u * nthr);
+      if (OP == RA_OP_PREMULSUM) {
+#pragma unroll
+        for (int j = 0; j < NSA; j++)
+          if (j == a.preIdx) {
+#pragma unroll
+            for (int u = 0; u < U; u++) v[j][u] = packPre<T>(v[j][u], a.opArg);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = v[0][u];
+#pragma unroll
+      for (int j = 1; j < NSA; j++)
+#pragma unroll
+        for (int u = 0; u < U; u++) acc[u] = packRed<T, OP>(acc[u], v[j][u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        acc[u] = ldPack(s[0] + i0 + (size_t)u * nthr);
+        if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc[u] = packPre<T>(acc[u], a.opArg);
+      }
+      for (int j = 1; j < a.ns; j++) {
+        const u32x4* sj = (const u32x4*)a.src[j];
+        u32x4 t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) t[u] = ldPack(sj + i0 + (size_t)u * nthr);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          if (OP == RA_OP_PREMULSUM && a.preIdx == j) t[u] = packPre<T>(t[u], a.opArg);
+          acc[u] = packRed<T, OP>(acc[u], t[u]);
+        }
+      }
+    }
+    if (OP == RA_OP_SUMPOSTDIV && a.post) {
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], a.opArg);
+    }
+    for (int k = 0; k < a.nd; k++) {
+      u32x4* d = (u32x4*)a.dst[k];
+#pragma unroll
+      for (int u = 0; u < U; u++) stPack(d + i0 + (size_t)u * nthr, acc[u]);
+    }
+  }
+  // Ragged end: the one tile that is not full, one pack per thread per pass.  Only the
+  // workgroup whose walk reaches it handles it.
+  if (base < npacks) {
+    for (size_t i = base + tid; i < npacks; i += nthr) {
+      u32x4 acc = ldPack((const u32x4*)a.src[0] + i);
+      if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc = packPre<T>(acc, a.opArg);
+      for (int j = 1; j < a.ns; j++) {
+        u32x4 t = ldPack((const u32x4*)a.src[j] + i);
+        if (OP == RA_OP_PREMULSUM && a.preIdx == j) t = packPre<T>(t, a.opArg);
+        acc = packRed<T, OP>(acc, t);
+      }
+      if (OP == RA_OP_SUMPOSTDIV && a.post) acc = packPost<T>(acc, a.opArg);
+      for (int k = 0; k < a.nd; k++) stPack((u32x4*)a.dst[k] + i, acc);
+    }
+  }
+}
+
+// Elements [first, nelem) one at a time (unaligned pointers, or the sub-pack tail).
+template <typename T, int OP>
+__device__ __forceinline__ void rcElems(const RcArgs& a, size_t nelem, size_t first, size_t step, int tid) {
+  constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+  for (size_t i = first + tid; i < nelem; i += step) {
+    T acc = ((const T*)a.src[0])[i];
+    if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc = Scale<T>::pre(acc, a.opArg);
+    for (int j = 1; j < a.ns; j++) {
+      T t = ((const T*)a.src[j])[i];
+      if (OP == RA_OP_PREMULSUM && a.preIdx == j) t = Scale<T>::pre(t, a.opArg);
+      acc = Elem<T, R>::red(acc, t);
+    }
+    if (OP == RA_OP_SUMPOSTDIV && a.post) acc = Scale<T>::post(acc, a.opArg);
+    for (int k = 0; k < a.nd; k++) ((T*)a.dst[k])[i] = acc;
+  }
+}
+
+__device__ __forceinline__ bool rcAligned(const RcArgs& a) {
+  uintptr_t m = 0;
+  for (int j = 0; j < a.ns; j++) m |= (uintptr_t)a.src[j];
+  for (int k = 0; k < a.nd; k++) m |= (uintptr_t)a.dst[k];
+  return (m & 15) == 0;
+}
+
+// One source-count case: full tiles of nthr*U packs are dealt round-robin to the `nparts`
+// workgroups taking part; the ragged last tile goes to whoever owns that tile index.
+template <typename T, int OP, int NS, int U>
+__device__ __forceinline__ void rcCase(const RcArgs& a, size_t npacks, int tid, int nthr, int part, int nparts) {
+  const size_t tile = (size_t)nthr * U;
+  const size_t nfull = npacks / tile;
+  const bool ownsRagged = (nfull % nparts) == (size_t)part;
+  const size_t lim = ownsRagged ? npacks : nfull * tile;
+  rcPacks<T, OP, NS, U>(a, lim, (size_t)part * tile, (size_t)nparts * tile, tid, nthr);
+}
+
+// Work-shared reduce-copy of `nelem` elements.  `part` of `nparts` workgroups take part
+// (the collectives use one workgroup: part 0 of 1; the local kernels use the whole grid).
+template <typename T, int OP>
+__device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int tid, int nthr, int part, int nparts) {
+  if (nelem == 0 || a.nd == 0) return;
+  if (rcAligned(a)) {
+    const size_t npacks = nelem * sizeof(T) / 16;
+    switch (a.ns) {
+      case 1: rcCase<T, OP, 1, 4>(a, npacks, tid, nthr, part, nparts); break;
+      case 2: rcCase<T, OP, 2, 4>(a, npacks, tid, nthr, part, nparts); break;
+      case 4: rcCase<T, OP, 4, 2>(a, npacks, tid, nthr, part, nparts); break;
+      case 8: rcCase<T, OP, 8, 2>(a, npacks, tid, nthr, part, nparts); break;
+      default: rcCase<T, OP, 0, 2>(a, npacks, tid, nthr, part, nparts); break;
+    }
+    const size_t done = npacks * (16 / sizeof(T));
+    if (done < nelem && part == 0) rcElems<T, OP>(a, nelem, done, nthr, tid);
+  } else {
+    rcElems<T, OP>(a, nelem, (size_t)part * nthr, (size_t)nparts * nthr, tid);
+  }
+}
+
+// The two entry points the collective schedules call, kept out of line so that each
+// (type, op) pair carries one copy of the loops however many schedule steps use them.
+template <typename T, int OP>
+__device__ __noinline__ void rcWG(const RcArgs& a, size_t nelem, int tid, int nthr) {
+  reduceCopy<T, OP>(a, nelem, tid, nthr, 0, 1);
+}
+// One source to a.nd destinations, any element type.
+static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int tid, int nthr) {
+  if (nbytes == 0 || a.nd == 0) return;
+  if (rcAligned(a)) {
+    rcCase<int8_t, RA_OP_SUM, 1, 4>(a, nbytes / 16, tid, nthr, 0, 1);
+    const size_t done = nbytes & ~(size_t)15;
+    if (done < nbytes) rcElems<int8_t, RA_OP_SUM>(a, nbytes, done, nthr, tid);
+  } else {
+    rcElems<int8_t, RA_OP_SUM>(a, nbytes, 0, nthr, tid);
+  }
+}
+
+// ------------------------------------------------------------------ local kernels
+// One rank (src/device/onerank.cu) and the exported N-source reduce-copy.
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void raLocalKernel(RcArgs a, size_t nelem) {
+  reduceCopy<T, OP>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------ inter-GPU protocol
+__device__ __forceinline__ uint64_t ldFlag(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void stFlag(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void drainVmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct ChanShared {
+  uint64_t sendStep[RA_MAX_RANKS][RA_NKINDS];
+  uint64_t recvStep[RA_MAX_RANKS][RA_NKINDS];
+  uint32_t sendDirty[RA_NKINDS];
+  uint32_t recvDirty[RA_NKINDS];
+  int aborted;
+};
+
+struct Ctx {
+  const RaDevComm* comm;
+  ChanShared* sh;
+  int ch, tid, nthr, rank, nRanks;
+
+  __device__ __forceinline__ uint64_t* flag(int owner, int which, int peer, int kind) const {
+    return (uint64_t*)(comm->win[owner] + raFlagOffset(comm->lay, which, ch, peer, kind));
+  }
+  // Slot I fill next on the FIFO towards `peer` (it lives in peer's window).
+  __device__ __forceinline__ char* sendSlot(int peer, int kind) const {
+    return comm->win[peer] + raDataOffset(comm->lay, ch, rank, kind) +
+           (sh->sendStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
+  }
+  // Slot I drain next on the FIFO from `peer` (it lives in my window).
+  __device__ __forceinline__ const char* recvSlot(int peer, int kind) const {
+    return comm->win[rank] + raDataOffset(comm->lay, ch, peer, kind) +
+           (sh->recvStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
+  }
+
+  __device__ void init(const RaDevComm* c, ChanShared* s, int channel) {
+    comm = c; sh = s; ch = channel; tid = threadIdx.x; nthr = blockDim.x; rank = c->rank; nRanks = c->nRanks;
+    const int n = nRanks * RA_NKINDS;
+    if (tid < n) {
+      const size_t ix = (size_t)ch * n + tid;
+      sh->sendStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->sendStep[ix];
+      sh->recvStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->recvStep[ix];
+    }
+    if (tid == 0) {
+      sh->aborted = 0;
+      for (int k = 0; k < RA_NKINDS; k++) { sh->sendDirty[k] = 0; sh->recvDirty[k] = 0; }
+    }
+    __syncthreads();
+  }
+  // Persist the step counters this workgroup advanced.
+  __device__ void finish() {
+    __syncthreads();
+    const int n = nRanks * RA_NKINDS;
+    if (tid < n) {
+      const int p = tid / RA_NKINDS, k = tid % RA_NKINDS;
+      const size_t ix = (size_t)ch * n + tid;
+      if (sh->sendDirty[k] >> p & 1) comm->sendStep[ix] = sh->sendStep[p][k];
+      if (sh->recvDirty[k] >> p & 1) comm->recvStep[ix] = sh->recvStep[p][k];
+    }
+  }
+
+  __device__ void spin(const uint64_t* f, uint64_t want) {
+    if (sh->aborted) return;
+    const uint64_t t0 = wall_clock64();
+    uint32_t spins = 0;
+    while (ldFlag(f) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 0x3ff) == 0) {
+        const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        const bool late = wall_clock64() - t0 > comm->timeoutTicks;
+        if (asked || late || sh->aborted) {
+          sh->aborted = 1;
+          uint32_t expect = RA_ERR_NONE;
+          __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
+                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          return;
+        }
+      }
+    }
+  }
+
+  // One protocol step.  recvMask/sendMask: bit p set = peer p takes part.  Lane p of wave 0
+  // waits for peer p's data (tail), lane 16+p waits for a free slot towards peer p (head).
+  // `body()` runs on all threads between the waits and the posts; it reads recvSlot()s and
+  // fills sendSlot()s.  Returns false once the communicator was aborted.
+  template <class F>
+  __device__ __forceinline__ bool step(uint32_t recvMask, int rk, uint32_t sendMask, int sk, F&& body) {
+    if (tid < RA_MAX_RANKS) {
+      if (recvMask >> tid & 1) {
+        spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      }
+    } else if (tid < 2 * RA_MAX_RANKS) {
+      const int p = tid - RA_MAX_RANKS;
+      if (sendMask >> p & 1) {
+        const uint64_t need = sh->sendStep[p][sk] + 1;   // slots published once this one is
+        if (need > (uint64_t)comm->lay.nSlots) spin(flag(rank, 1, p, sk), need - comm->lay.nSlots);
+      }
+    }
+    if (tid < 64) drainVmem();
+    __syncthreads();
+    const bool ok = !sh->aborted;
+    if (ok) body();
+    drainVmem();       // every wave: its loads have returned and its stores are acknowledged
+    __syncthreads();
+    if (tid < 64) {
+      if (sendMask) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); drainVmem(); }
+      if (tid < RA_MAX_RANKS) {
+        if (recvMask >> tid & 1) {          // slot consumed: credit to the sender (its window)
+          const uint64_t s = sh->recvStep[tid][rk] + 1;
+          sh->recvStep[tid][rk] = s;
+          if (ok) stFlag(flag(tid, 1, rank, rk), s);
+        }
+      } else if (tid < 2 * RA_MAX_RANKS) {
+        const int p = tid - RA_MAX_RANKS;
+        if (sendMask >> p & 1) {            // slot published: tail in the receiver's window
+          const uint64_t s = sh->sendStep[p][sk] + 1;
+          sh->sendStep[p][sk] = s;
+          if (ok) stFlag(flag(p, 0, rank, sk), s);
+        }
+      }
+      if (tid == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
+    }
+    __syncthreads();
+    return ok;
+  }
+};
+
+// Round geometry shared by the all-reduce schedules: the buffer is cut into rounds of
+// nRanks*chunk elements; channel c owns rounds c, c+C, ...; inside a round, piece j
+// starts at j*chunk.  The final round uses lastChunkElems so that its pieces stay balanced
+// (reference: src/enqueue.cc:277-297, src/device/all_reduce.h:75).
+struct Rounds {
+  size_t count, chunk, lastChunk, roundElems, nRounds;
+  int n;
+  __device__ Rounds(const RaWork& w, int nRanks) {
+    n = nRanks; count = w.count; chunk = w.chunkElems; lastChunk = w.lastChunkElems;
+    roundElems = (size_t)n * chunk;
+    nRounds = (count + roundElems - 1) / roundElems;
+  }
+  __device__ __forceinline__ void piece(size_t g, int j, size_t& off, size_t& nelem) const {
+    const size_t base = g * roundElems;
+    const size_t ck = (g + 1 == nRounds) ? lastChunk : chunk;
+    off = base + (size_t)j * ck;
+    const size_t end = off + ck < count ? off + ck : count;
+    nelem = off < count ? end - off : 0;
+    if (off > count) off = count;
+  }
+};
+
+__device__ __forceinline__ uint32_t peersMask(int nRanks, int rank) { return ((1u << nRanks) - 1u) & ~(1u << rank); }
+
+// ------------------------------------------------------------------ direct (all-pairs) schedules
+// All-reduce.  Piece j of every round is owned by rank j.  Three roles per channel:
+//   scatter : push my input of piece p into p's window (kind 0), for every peer p
+//   reduce  : fold my own piece with the n-1 arrivals in rank order, write it to recvbuff
+//             and push it into every peer's window (kind 1)
+//   gather  : copy the n-1 finished pieces that arrive (kind 1) into recvbuff
+template <typename T, int OP>
+__device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks, r = cx.rank;
+  const Rounds R(w, n);
+  const uint32_t peers = peersMask(n, r);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
+    if (role == 0) {
+      cx.step(0, 0, peers, 0, [&]() {
+        for (int i = 1; i < n; i++) {
+          const int p = (r + i) % n;
+          size_t off, ne; R.piece(g, p, off, ne);
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0);
+          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        }
+      });
+    } else if (role == 1) {
+      cx.step(peers, 0, peers, 1, [&]() {
+        size_t off, ne; R.piece(g, r, off, ne);
+        RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
+        for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
+        a.dst[0] = (char*)(out + off);
+        int k = 1;
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      });
+    } else {
+      cx.step(peers, 1, 0, 0, [&]() {
+        for (int i = 1; i < n; i++) {
+          const int p = (r + n - i) % n;
+          size_t off, ne; R.piece(g, p, off, ne);
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = (char*)(out + off);
+          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+        }
+      });
+    }
+  }
+}
+
+// Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers
+// elements [g*chunk, (g+1)*chunk) of every block.  Roles: scatter, reduce.
+template <typename T, int OP>
+__device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks, r = cx.rank;
+  const uint32_t peers = peersMask(n, r);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * w.chunkElems;
+    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    if (role == 0) {
+      cx.step(0, 0, peers, 0, [&]() {
+        for (int i = 1; i < n; i++) {
+          const int p = (r + i) % n;
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0);
+          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        }
+      });
+    } else {
+      cx.step(peers, 0, 0, 0, [&]() {
+        RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
+        for (int j = 0; j < n; j++)
+          a.src[j] = (j == r) ? (const char*)(in + (size_t)r * w.count + off) : cx.recvSlot(j, 0);
+        a.dst[0] = (char*)(out + off);
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      });
+    }
+  }
+}
+
+// All-gather (bytes): roles: spread (my block into every peer's window and into my own
+// recvbuff slot unless in place), gather.
+__device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks, r = cx.rank;
+  const uint32_t peers = peersMask(n, r);
+  const size_t nbytes = w.count * w.elemSize;          // per rank
+  const size_t chunkB = w.chunkElems * w.elemSize;
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * chunkB;
+    const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    if (role == 0) {
+      cx.step(0, 0, peers, 1, [&]() {
+        RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+        a.src[0] = w.send + off;
+        int k = 0;
+        char* mine = w.recv + (size_t)r * nbytes + off;
+        if (mine != w.send + off) a.dst[k++] = mine;
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
+        a.nd = k;
+        copyWG(a, nb, cx.tid, cx.nthr);
+      });
+    } else {
+      cx.step(peers, 1, 0, 0, [&]() {
+        for (int i = 1; i < n; i++) {
+          const int p = (r + n - i) % n;
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = w.recv + (size_t)p * nbytes + off;
+          copyWG(a, nb, cx.tid, cx.nthr);
+        }
+      });
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ring schedules
+// Same walk as the reference ring (src/device/all_reduce.h:71-199): in a round, the piece
+// with ring index c is seeded at ring position c+1, gains one rank's input per hop and is
+// finished at position c, which also starts its circulation.  One workgroup per channel.
+struct RingPos {
+  int ix, prev, next;
+  const int8_t* order;
+  __device__ RingPos(const Ctx& cx) {
+    order = cx.comm->ringRanks[cx.ch % cx.comm->nRings];
+    ix = 0;
+    for (int i = 0; i < cx.nRanks; i++) if (order[i] == cx.rank) ix = i;
+    prev = order[(ix + cx.nRanks - 1) % cx.nRanks];
+    next = order[(ix + 1) % cx.nRanks];
+  }
+};
+
+template <typename T, int OP>
+__device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
+  const int n = cx.nRanks;
+  const Rounds R(w, n);
+  const RingPos rp(cx);
+  const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
+    size_t off, ne;
+    // step 0: seed the piece behind me
+    R.piece(g, (rp.ix + n - 1) % n, off, ne);
+    cx.step(0, 0, nm, 0, [&]() {
+      RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+    });
+    // n-2 hops: local + received -> next
+    for (int j = 2; j < n; j++) {
+      R.piece(g, (rp.ix + n - j) % n, off, ne);
+      cx.step(pm, 0, nm, 0, [&]() {
+        RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+        a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+        a.dst[0] = cx.sendSlot(rp.next, 0);
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      });
+    }
+    // my own piece: final value, kept and sent on
+    R.piece(g, rp.ix, off, ne);
+    cx.step(pm, 0, nm, 0, [&]() {
+      RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
+      a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+      a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+    });
+    // n-2 hops: keep and forward finished pieces
+    for (int j = 1; j < n - 1; j++) {
+      R.piece(g, (rp.ix + n - j) % n, off, ne);
+      cx.step(pm, 0, nm, 0, [&]() {
+        RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
+        a.src[0] = cx.recvSlot(rp.prev, 0);
+        a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0);
+        copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+      });
+    }
+    // last finished piece
+    R.piece(g, (rp.ix + 1) % n, off, ne);
+    cx.step(pm, 0, 0, 0, [&]() {
+      RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = (char*)(out + off);
+      copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+    });
+  }
+}
+
+// Ring reduce-scatter (src/device/reduce_scatter.h:36-57): blocks travel in the order
+// order[n-1], ..., order[0] relative to each rank's rotated ring and finish at their owner.
+template <typename T, int OP>
+__device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
+  const int n = cx.nRanks;
+  const RingPos rp(cx);
+  const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * w.chunkElems;
+    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    int blk = rp.order[(rp.ix + n - 1) % n];
+    cx.step(0, 0, nm, 0, [&]() {
+      RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+    });
+    for (int j = 2; j < n; j++) {
+      blk = rp.order[(rp.ix + n - j) % n];
+      cx.step(pm, 0, nm, 0, [&]() {
+        RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+        a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+        a.dst[0] = cx.sendSlot(rp.next, 0);
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      });
+    }
+    cx.step(pm, 0, 0, 0, [&]() {
+      RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
+      a.src[0] = (const char*)(in + (size_t)cx.rank * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+      a.dst[0] = (char*)(out + off);
+      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+    });
+  }
+}
+
+// Ring all-gather (src/device/all_gather.h:69-145), bytes.
+__device__ void ringAllGather(Ctx& cx, const RaWork& w) {
+  const int n = cx.nRanks;
+  const RingPos rp(cx);
+  const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
+  const size_t nbytes = w.count * w.elemSize;
+  const size_t chunkB = w.chunkElems * w.elemSize;
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * chunkB;
+    const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    cx.step(0, 0, nm, 0, [&]() {
+      RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+      a.src[0] = w.send + off;
+      int k = 0;
+      char* mine = w.recv + (size_t)cx.rank * nbytes + off;
+      if (mine != w.send + off) a.dst[k++] = mine;
+      a.dst[k++] = cx.sendSlot(rp.next, 0);
+      a.nd = k;
+      copyWG(a, nb, cx.tid, cx.nthr);
+    });
+    for (int j = 1; j < n - 1; j++) {
+      const int blk = rp.order[(rp.ix + n - j) % n];
+      cx.step(pm, 0, nm, 0, [&]() {
+        RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
+        a.src[0] = cx.recvSlot(rp.prev, 0);
+        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.dst[1] = cx.sendSlot(rp.next, 0);
+        copyWG(a, nb, cx.tid, cx.nthr);
+      });
+    }
+    const int blk = rp.order[(rp.ix + 1) % n];
+    cx.step(pm, 0, 0, 0, [&]() {
+      RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = w.recv + (size_t)blk * nbytes + off;
+      copyWG(a, nb, cx.tid, cx.nthr);
+    });
+  }
+}
+
+// ------------------------------------------------------------------ chain ("tree") all-reduce
+// Inside a node the reference's tree is a chain in ring order (src/graph/connect.cc:61-62):
+// order[0] is the root, order[n-1] the leaf.  Up (kind 0): leaf sends, middles compute
+// local + received, the root finishes (src/device/all_reduce.h:269-289).  Down (kind 1): the
+// finished chunk travels back (all_reduce.h:318-338).  Two roles per channel so that the up
+// and down pipelines overlap: role 0 runs the up steps (the root's up step also starts the
+// way down), role 1 runs the down steps.  Round g covers elements [g*chunk, (g+1)*chunk).
+template <typename T, int OP>
+__device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks;
+  const RingPos rp(cx);
+  const bool root = rp.ix == 0, leaf = rp.ix == n - 1;
+  const int parent = rp.prev, child = rp.next;
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * w.chunkElems;
+    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    if (role == 0) {
+      if (leaf) {
+        cx.step(0, 0, 1u << parent, 0, [&]() {
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0);
+          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        });
+      } else if (!root) {
+        cx.step(1u << child, 0, 1u << parent, 0, [&]() {
+          RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+          a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
+          a.dst[0] = cx.sendSlot(parent, 0);
+          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        });
+      } else {
+        cx.step(1u << child, 0, 1u << child, 1, [&]() {
+          RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
+          a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
+          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1);
+          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        });
+      }
+    } else {
+      if (root) continue;
+      if (leaf) {
+        cx.step(1u << parent, 1, 0, 0, [&]() {
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+          a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = (char*)(out + off);
+          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+        });
+      } else {
+        cx.step(1u << parent, 1, 1u << child, 1, [&]() {
+          RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
+          a.src[0] = cx.recvSlot(parent, 1);
+          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1);
+          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+        });
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the collective kernel
+// grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.
+template <typename T, int OP>
+__global__ __launch_bounds__(512) void raCollKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  __shared__ ChanShared sh;
+  Ctx cx;
+  const int role = blockIdx.x / w.nChannels;
+  cx.init(comm, &sh, blockIdx.x % w.nChannels);
+  if (w.algo == RA_ALGO_DIRECT) {
+    if (w.coll == RA_COLL_ALLREDUCE) directAllReduce<T, OP>(cx, w, role);
+    else if (w.coll == RA_COLL_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);
+  } else if (w.algo == RA_ALGO_RING) {
+    if (w.coll == RA_COLL_ALLREDUCE) ringAllReduce<T, OP>(cx, w);
+    else if (w.coll == RA_COLL_REDUCESCATTER) ringReduceScatter<T, OP>(cx, w);
+  } else {
+    if (w.coll == RA_COLL_ALLREDUCE) chainAllReduce<T, OP>(cx, w, role);
+  }
+  cx.finish();
+}
+

@@ -1,0 +1,265 @@
+"""ctypes mirror of include/rccl_amd.h — same names, argument order and error convention as
+the reference's public header (ROCm/rccl src/nccl.h.in).
+
+There is no fallback: if librccl_amd.so is missing or does not load, importing this module
+raises.  Buffers are raw device pointers (int) or torch tensors (their data_ptr is used);
+streams are hipStream_t handles (int) or torch streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librccl_amd.so")
+
+# ncclResult_t (nccl.h.in:50-60)
+ncclSuccess, ncclUnhandledCudaError, ncclSystemError, ncclInternalError = 0, 1, 2, 3
+ncclInvalidArgument, ncclInvalidUsage, ncclRemoteError, ncclInProgress = 4, 5, 6, 7
+# ncclRedOp_t (nccl.h.in:353-358)
+ncclSum, ncclProd, ncclMax, ncclMin, ncclAvg, ncclNumOps = 0, 1, 2, 3, 4, 5
+# ncclDataType_t (nccl.h.in:364-377)
+ncclInt8, ncclUint8, ncclInt32, ncclUint32, ncclInt64, ncclUint64 = 0, 1, 2, 3, 4, 5
+ncclFloat16, ncclFloat32, ncclFloat64, ncclBfloat16, ncclFp8E4M3, ncclFp8E5M2 = 6, 7, 8, 9, 10, 11
+ncclChar, ncclInt, ncclHalf, ncclFloat, ncclDouble = ncclInt8, ncclInt32, ncclFloat16, ncclFloat32, ncclFloat64
+ncclScalarDevice, ncclScalarHostImmediate = 0, 1
+NCCL_UNIQUE_ID_BYTES = 128
+
+TYPE_SIZE = {ncclInt8: 1, ncclUint8: 1, ncclInt32: 4, ncclUint32: 4, ncclInt64: 8, ncclUint64: 8,
+             ncclFloat16: 2, ncclFloat32: 4, ncclFloat64: 8, ncclBfloat16: 2, ncclFp8E4M3: 1, ncclFp8E5M2: 1}
+
+EXPORTS = [
+    "ncclGetVersion", "ncclGetErrorString", "ncclGetLastError", "ncclCommGetAsyncError", "ncclGetUniqueId",
+    "ncclCommInitRankConfig", "ncclCommInitRank", "ncclCommInitAll", "ncclCommFinalize", "ncclCommDestroy",
+    "ncclCommAbort", "ncclCommCount", "ncclCommCuDevice", "ncclCommUserRank", "ncclMemAlloc", "ncclMemFree",
+    "ncclRedOpCreatePreMulSum", "ncclRedOpDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather",
+    "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
+    "ncclCommSplit", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
+]
+
+
+class ncclUniqueId(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+class ncclConfig_t(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_size_t), ("magic", ctypes.c_uint), ("version", ctypes.c_uint),
+                ("blocking", ctypes.c_int), ("cgaClusterSize", ctypes.c_int), ("minCTAs", ctypes.c_int),
+                ("maxCTAs", ctypes.c_int), ("netName", ctypes.c_char_p), ("splitShare", ctypes.c_int)]
+
+
+class NcclError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().ncclGetErrorString(code).decode()
+        last = lib().ncclGetLastError(None).decode()
+        super().__init__(f"{where}: {msg} [{code}] {last}")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises OSError when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: build it with `make -C rccl_amd/csrc -j8` "
+                          "(or __graft_entry__.build()); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetErrorString.argtypes = [ci]
+        L.ncclGetLastError.restype = ctypes.c_char_p
+        L.ncclGetLastError.argtypes = [vp]
+        L.ncclGetVersion.argtypes = [ctypes.POINTER(ci)]
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(ncclUniqueId)]
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), ci, ncclUniqueId, ci]
+        L.ncclCommInitRankConfig.argtypes = [ctypes.POINTER(vp), ci, ncclUniqueId, ci, ctypes.POINTER(ncclConfig_t)]
+        L.ncclCommInitAll.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ci)]
+        for f in ("ncclCommFinalize", "ncclCommDestroy", "ncclCommAbort"):
+            getattr(L, f).argtypes = [vp]
+        for f in ("ncclCommCount", "ncclCommCuDevice", "ncclCommUserRank", "ncclCommGetAsyncError"):
+            getattr(L, f).argtypes = [vp, ctypes.POINTER(ci)]
+        L.ncclMemAlloc.argtypes = [ctypes.POINTER(vp), sz]
+        L.ncclMemFree.argtypes = [vp]
+        L.ncclRedOpCreatePreMulSum.argtypes = [ctypes.POINTER(ci), vp, ci, ci, vp]
+        L.ncclRedOpDestroy.argtypes = [ci, vp]
+        L.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        L.ncclReduceScatter.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        L.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
+        L.ncclGroupStart.argtypes = []
+        L.ncclGroupEnd.argtypes = []
+        L.ncclReduce.argtypes = [vp, vp, sz, ci, ci, ci, vp, vp]
+        L.ncclBroadcast.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        L.ncclBcast.argtypes = [vp, sz, ci, ci, vp, vp]
+        L.ncclSend.argtypes = [vp, sz, ci, ci, vp, vp]
+        L.ncclRecv.argtypes = [vp, sz, ci, ci, vp, vp]
+        L.ncclCommSplit.argtypes = [vp, ci, ci, ctypes.POINTER(vp), vp]
+        L.rcclAmdReduceCopy.argtypes = [vp, ctypes.POINTER(vp), ci, sz, ci, ci, vp]
+        L.rcclAmdTopoRings.argtypes = [ci, ctypes.POINTER(ci), ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.rcclAmdTopoParseXml.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.rcclAmdPlanInfo.argtypes = [vp, ci, sz, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                      ctypes.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != ncclSuccess:
+        raise NcclError(code, where)
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    return ctypes.c_void_p(x.data_ptr())      # torch tensor
+
+
+def _stream(s):
+    if s is None:
+        import torch
+        s = torch.cuda.current_stream()
+    if isinstance(s, int):
+        return ctypes.c_void_p(s)
+    return ctypes.c_void_p(s.cuda_stream)     # torch.cuda.Stream
+
+
+def get_version():
+    v = ctypes.c_int()
+    _check(lib().ncclGetVersion(ctypes.byref(v)), "ncclGetVersion")
+    return v.value
+
+
+def get_unique_id():
+    """ncclGetUniqueId -> 128 opaque bytes to hand to every rank."""
+    uid = ncclUniqueId()
+    _check(lib().ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+    return ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)
+
+
+def group_start():
+    _check(lib().ncclGroupStart(), "ncclGroupStart")
+
+
+def group_end():
+    _check(lib().ncclGroupEnd(), "ncclGroupEnd")
+
+
+class Communicator:
+    """One rank's ncclComm_t."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @classmethod
+    def init_rank(cls, nranks, unique_id, rank, blocking=None):
+        """ncclCommInitRank / ncclCommInitRankConfig on the current HIP device."""
+        uid = ncclUniqueId()
+        ctypes.memmove(ctypes.byref(uid), unique_id, NCCL_UNIQUE_ID_BYTES)
+        h = ctypes.c_void_p()
+        if blocking is None:
+            _check(lib().ncclCommInitRank(ctypes.byref(h), nranks, uid, rank), "ncclCommInitRank")
+        else:
+            cfg = ncclConfig_t(ctypes.sizeof(ncclConfig_t), 0xcafebeef, 22105, int(blocking), -2**31, -2**31, -2**31,
+                               None, -2**31)
+            _check(lib().ncclCommInitRankConfig(ctypes.byref(h), nranks, uid, rank, ctypes.byref(cfg)),
+                   "ncclCommInitRankConfig")
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, ndev, devlist=None):
+        """ncclCommInitAll: one communicator per entry of devlist, all in this process."""
+        hs = (ctypes.c_void_p * ndev)()
+        dl = None if devlist is None else (ctypes.c_int * ndev)(*devlist)
+        _check(lib().ncclCommInitAll(hs, ndev, dl), "ncclCommInitAll")
+        return [cls(ctypes.c_void_p(h)) for h in hs]
+
+    def _int(self, fn):
+        v = ctypes.c_int()
+        _check(getattr(lib(), fn)(self.handle, ctypes.byref(v)), fn)
+        return v.value
+
+    def count(self):
+        return self._int("ncclCommCount")
+
+    def user_rank(self):
+        return self._int("ncclCommUserRank")
+
+    def cu_device(self):
+        return self._int("ncclCommCuDevice")
+
+    def async_error(self):
+        return self._int("ncclCommGetAsyncError")
+
+    def all_reduce(self, sendbuff, recvbuff, count, datatype, op=ncclSum, stream=None):
+        _check(lib().ncclAllReduce(_ptr(sendbuff), _ptr(recvbuff), count, datatype, op, self.handle, _stream(stream)),
+               "ncclAllReduce")
+
+    def reduce_scatter(self, sendbuff, recvbuff, recvcount, datatype, op=ncclSum, stream=None):
+        _check(lib().ncclReduceScatter(_ptr(sendbuff), _ptr(recvbuff), recvcount, datatype, op, self.handle,
+                                       _stream(stream)), "ncclReduceScatter")
+
+    def all_gather(self, sendbuff, recvbuff, sendcount, datatype, stream=None):
+        _check(lib().ncclAllGather(_ptr(sendbuff), _ptr(recvbuff), sendcount, datatype, self.handle, _stream(stream)),
+               "ncclAllGather")
+
+    def create_premul_sum(self, scalar_bytes, datatype, residence=ncclScalarHostImmediate, device_ptr=None):
+        """ncclRedOpCreatePreMulSum; scalar_bytes holds the scalar in `datatype`."""
+        op = ctypes.c_int()
+        if residence == ncclScalarHostImmediate:
+            buf = ctypes.create_string_buffer(bytes(scalar_bytes), 8)
+            p = ctypes.cast(buf, ctypes.c_void_p)
+        else:
+            p = ctypes.c_void_p(device_ptr)
+        _check(lib().ncclRedOpCreatePreMulSum(ctypes.byref(op), p, datatype, residence, self.handle),
+               "ncclRedOpCreatePreMulSum")
+        return op.value
+
+    def destroy_op(self, op):
+        _check(lib().ncclRedOpDestroy(op, self.handle), "ncclRedOpDestroy")
+
+    def plan_info(self, coll, count, datatype):
+        a, p, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        ch = ctypes.c_size_t()
+        _check(lib().rcclAmdPlanInfo(self.handle, coll, count, datatype, ctypes.byref(a), ctypes.byref(p),
+                                     ctypes.byref(c), ctypes.byref(ch)), "rcclAmdPlanInfo")
+        return {"algo": a.value, "proto": p.value, "nChannels": c.value, "chunkElems": ch.value}
+
+    def finalize(self):
+        _check(lib().ncclCommFinalize(self.handle), "ncclCommFinalize")
+
+    def destroy(self):
+        if self.handle:
+            _check(lib().ncclCommDestroy(self.handle), "ncclCommDestroy")
+            self.handle = None
+
+    def abort(self):
+        if self.handle:
+            _check(lib().ncclCommAbort(self.handle), "ncclCommAbort")
+            self.handle = None
+
+
+def reduce_copy(dst, srcs, count, datatype, op=ncclSum, stream=None):
+    """rcclAmdReduceCopy: dst = fold of srcs (device pointers or tensors) on the current device."""
+    arr = (ctypes.c_void_p * len(srcs))(*[_ptr(s).value for s in srcs])
+    _check(lib().rcclAmdReduceCopy(_ptr(dst), arr, len(srcs), count, datatype, op, _stream(stream)),
+           "rcclAmdReduceCopy")
+
+
+def topo_rings(ngpus, adj, max_rings=64):
+    """rcclAmdTopoRings: list of rings (each a list of ngpus ranks) for a 0/1 adjacency matrix."""
+    flat = (ctypes.c_int * (ngpus * ngpus))(*[int(x) for row in adj for x in row])
+    out = (ctypes.c_int * (max_rings * ngpus))()
+    n = ctypes.c_int()
+    _check(lib().rcclAmdTopoRings(ngpus, flat, max_rings, out, ctypes.byref(n)), "rcclAmdTopoRings")
+    return [[out[i * ngpus + j] for j in range(ngpus)] for i in range(n.value)]
+
+
+def topo_parse_xml(text, max_gpus=16):
+    """rcclAmdTopoParseXml: xGMI adjacency matrix of a topology XML in the reference's format."""
+    adj = (ctypes.c_int * (max_gpus * max_gpus))()
+    n = ctypes.c_int()
+    _check(lib().rcclAmdTopoParseXml(text.encode(), max_gpus, adj, ctypes.byref(n)), "rcclAmdTopoParseXml")
+    k = n.value
+    return [[adj[i * k + j] for j in range(k)] for i in range(k)]

@@ -1,0 +1,151 @@
+"""GPU parity of ncclAllReduce / ncclReduceScatter / ncclAllGather against the CPU oracle.
+
+Ranks are separate processes created with ncclCommInitRank (HIP IPC windows), several per GPU
+when the box has fewer GPUs than ranks — the reference's multi-process, ranks-per-GPU test mode
+(test/common/TestBed.cpp:564-583).  Cases follow the reference's own lists
+(test/AllReduceTests.cpp:10-130, test/ReduceScatterTests.cpp:10-120, test/AllGatherTests.cpp:10-120,
+test/StandaloneTests.cpp:191-246), with the largest sizes trimmed to keep the suite short.
+
+Bars: integer types and copies bit-exact; floating point bit-exact against the oracle's fold in the
+schedule's own association order AND within the reference tolerance (fp32 1e-5, fp64 1e-12,
+fp16/bf16 9e-2 absolute, test/common/PtrUnion.cpp:313-342) of the reference's rank-order host fold.
+"""
+import numpy as np
+import pytest
+
+import expected as ex
+import oracle as orc
+from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_REDUCESCATTER, TestBed
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = {"Direct": ex.ALGO_DIRECT, "Ring": ex.ALGO_RING, "Tree": ex.ALGO_TREE}
+
+
+def _devices():
+    import torch
+    return tuple(range(torch.cuda.device_count()))
+
+
+@pytest.fixture(scope="module", params=[2, 4, 8])
+def bed(request):
+    tb = TestBed(request.param, devices=_devices())
+    yield tb
+    tb.close()
+
+
+def _es(dt):
+    return np.dtype(orc.NP_OF[dt]).itemsize
+
+
+def _check_allreduce(bed, dt, op, count, in_place=False, pattern=True, seed=0):
+    n = bed.nranks
+    if pattern:
+        ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+    else:
+        rng = np.random.default_rng(seed)
+        ins = [rng.uniform(-1, 1, count).astype(np.float32) for _ in range(n)]
+    outs = bed.run(COLL_ALLREDUCE, dt, op, count, ins, count * _es(dt), in_place=in_place)
+    plan = bed.plan(COLL_ALLREDUCE, count, dt)
+    want = ex.allreduce(dt, op, ins, plan)
+    host = orc.host_fold(dt, op, ins)
+    for r in range(n):
+        assert ex.check(dt, outs[r], want, exact=True) is None, (r, ex.check(dt, outs[r], want, exact=True), plan)
+        assert ex.check(dt, outs[r], host, exact=False) is None, (r, "vs host fold", plan)
+
+
+@pytest.mark.parametrize("algo", list(ALGOS))
+def test_allreduce_cases(bed, algo):
+    bed.init_comms({"NCCL_ALGO": algo})
+    assert bed.plan(COLL_ALLREDUCE, 1 << 20, orc.F32)["algo"] == ALGOS[algo]
+    # known answer: int32 sum N=1250, in[i]=i on every rank -> nranks*i (StandaloneTests.cpp:191-246)
+    x = np.arange(1250, dtype=np.int32)
+    outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 1250, [x] * bed.nranks, 1250 * 4)
+    for o in outs:
+        assert np.array_equal(o.view(np.int32), bed.nranks * x)
+    # AllReduceTests.cpp:10-27 fp32 sum out of place
+    for count in (393216, 384):
+        _check_allreduce(bed, orc.F32, orc.SUM, count)
+    # :29-46 fp16/fp64 min
+    for dt in (orc.F16, orc.F64):
+        _check_allreduce(bed, dt, orc.MIN, 12888)
+    # :48-65 int32/int8 prod in place
+    for dt in (orc.I32, orc.I8):
+        _check_allreduce(bed, dt, orc.PROD, 384, in_place=True)
+    # :67-84 int32 max in place
+    _check_allreduce(bed, orc.I32, orc.MAX, 12888, in_place=True)
+    # :86-103 uint8/uint64 sum
+    for dt in (orc.U8, orc.U64):
+        _check_allreduce(bed, dt, orc.SUM, 2500)
+    # :105-130 bf16 sum, large (trimmed from 64 Mi elements)
+    _check_allreduce(bed, orc.BF16, orc.SUM, 3 * 1024 * 1024 + 1000)
+    # average: integer post-divide, float pre-multiply (enqueue.cc:2006-2044)
+    for dt in (orc.I64, orc.U8, orc.U32, orc.F32, orc.F16, orc.BF16, orc.F64):
+        _check_allreduce(bed, dt, orc.AVG, 70001)
+    # random fp32 data, several rounds per channel, ragged tail
+    _check_allreduce(bed, orc.F32, orc.SUM, 5 * 1024 * 1024 + 123, pattern=False, seed=5)
+
+
+def test_allreduce_premul_sum(bed):
+    """User-created pre-multiply-sum op with a different scalar per rank (AllReduceTests.cpp:176-243)."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n, count = bed.nranks, 50000
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    scal = [np.float32(1.0 / (r + 2)) for r in range(n)]
+    outs = bed.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4, premul=[s.tobytes() for s in scal])
+    want = orc.device_fold(orc.F32, orc.SUM, [a * s for a, s in zip(ins, scal)])
+    for o in outs:
+        assert np.array_equal(o.view(np.float32), want)
+
+
+@pytest.mark.parametrize("algo", ["Direct", "Ring"])
+def test_reduce_scatter_cases(bed, algo):
+    bed.init_comms({"NCCL_ALGO": algo})
+    n = bed.nranks
+    # ReduceScatterTests.cpp: fp32 max {393216,384}; fp64/bf16 max; int32 prod in place 542357 (trimmed);
+    # uint8/fp16 min in place 246; int64/uint8 avg 1024; uint32/uint64 avg (trimmed)
+    cases = [(orc.F32, orc.MAX, 393216, False), (orc.F32, orc.MAX, 384, False), (orc.F64, orc.MAX, 104857, False),
+             (orc.BF16, orc.MAX, 104857, False), (orc.I32, orc.PROD, 54235, True), (orc.U8, orc.MIN, 246, True),
+             (orc.F16, orc.MIN, 246, True), (orc.I64, orc.AVG, 1024, False), (orc.U8, orc.AVG, 1024, False),
+             (orc.U32, orc.AVG, 648541, False), (orc.U64, orc.AVG, 64853, False), (orc.F32, orc.SUM, 1048576 + 7, False)]
+    for dt, op, count, in_place in cases:
+        ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
+        outs = bed.run(COLL_REDUCESCATTER, dt, op, count, ins, count * _es(dt), in_place=in_place)
+        plan = bed.plan(COLL_REDUCESCATTER, count, dt)
+        for r in range(n):
+            want = ex.reduce_scatter(dt, op, ins, r, plan)
+            host = orc.reduce_scatter_expected(dt, op, ins, r)
+            assert ex.check(dt, outs[r], want, exact=True) is None, (orc.DT_NAMES[dt], orc.OP_NAMES[op], count, r, plan)
+            assert ex.check(dt, outs[r], host, exact=False) is None
+
+
+@pytest.mark.parametrize("algo", ["Direct", "Ring"])
+def test_all_gather_cases(bed, algo):
+    bed.init_comms({"NCCL_ALGO": algo})
+    n = bed.nranks
+    # AllGatherTests.cpp: fp16/fp32 {1048576,500}; bf16/fp64 586; int32 in place {104857,264}; int8/int64 in place 958;
+    # uint8 {1039203,2500}; uint32/uint64 896
+    cases = [(orc.F16, 1048576, False), (orc.F32, 500, False), (orc.BF16, 586, False), (orc.F64, 586, False),
+             (orc.I32, 104857, True), (orc.I32, 264, True), (orc.I8, 958, True), (orc.I64, 958, True),
+             (orc.U8, 1039203, False), (orc.U8, 2500, False), (orc.U32, 896, False), (orc.U64, 896, False)]
+    for dt, count, in_place in cases:
+        ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+        outs = bed.run(COLL_ALLGATHER, dt, orc.SUM, count, ins, count * n * _es(dt), in_place=in_place)
+        want = orc.all_gather_expected(ins)
+        for r in range(n):
+            assert ex.check(dt, outs[r], want, exact=True) is None, (orc.DT_NAMES[dt], count, in_place, r)
+
+
+def test_back_to_back_and_reinit(bed):
+    """Step counters persist across launches; communicators can be destroyed and recreated."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n, count = bed.nranks, 200000
+    ins = [orc.fill_pattern(orc.I32, count, r) for r in range(n)]
+    want = orc.host_fold(orc.I32, orc.SUM, ins)
+    outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, count, ins, count * 4, iters=5)
+    for o in outs:
+        assert np.array_equal(o.view(np.int32), want)
+    bed.init_comms({"NCCL_ALGO": None})
+    outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, count, ins, count * 4)
+    for o in outs:
+        assert np.array_equal(o.view(np.int32), want)

@@ -1,0 +1,190 @@
+"""Multi-process test bed: one child process per rank, driven over pipes by a command enum.
+
+Modelled on the reference's own test bed (test/common/TestBed.cpp:614-765 and
+test/common/TestBedChild.cpp:119-130: the parent forks one child per rank up front and
+sends GET_UNIQUE_ID / INIT_COMMS / SET_COLL_ARGS / EXECUTE_COLL / VALIDATE commands).
+Every child owns one communicator created with ncclCommInitRank; several ranks may share
+one GPU (the reference's ranks-per-GPU mode), which is how the inter-rank protocol is
+exercised on a one-GPU box.
+
+Children import torch and the HIP library; the parent only needs numpy.
+"""
+import multiprocessing as mp
+import os
+import traceback
+
+import numpy as np
+
+COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER = 0, 1, 2
+
+
+def _child(rank, nranks, device, conn, env):
+    try:
+        os.environ.update(env)
+        import torch
+        import rccl_amd as ra
+        torch.cuda.set_device(device)
+        comm = None
+        stream = torch.cuda.Stream()
+        while True:
+            cmd, args = conn.recv()
+            if cmd == "stop":
+                break
+            if cmd == "uid":
+                conn.send(("ok", ra.get_unique_id()))
+            elif cmd == "init":
+                uid, init_env = args
+                for k, v in init_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                comm = ra.Communicator.init_rank(nranks, uid, rank)
+                conn.send(("ok", (comm.count(), comm.user_rank(), comm.cu_device())))
+            elif cmd == "coll":
+                # args: dict(coll, dtype, op, count, input(np bytes), out_bytes, in_place, premul(bytes|None), iters)
+                a = args
+                inp = torch.from_numpy(np.frombuffer(a["input"], dtype=np.uint8).copy()).cuda()
+                es = ra.TYPE_SIZE[a["dtype"]]
+                if a["in_place"]:
+                    # buffer sized for the larger side; input placed where the API expects it
+                    nbytes = max(len(a["input"]), a["out_bytes"])
+                    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+                    if a["coll"] == COLL_ALLGATHER:
+                        off = rank * a["count"] * es
+                        buf[off:off + len(a["input"])] = inp
+                        send_ptr, recv_ptr = buf.data_ptr() + off, buf.data_ptr()
+                    elif a["coll"] == COLL_REDUCESCATTER:
+                        buf[:len(a["input"])] = inp
+                        send_ptr, recv_ptr = buf.data_ptr(), buf.data_ptr() + rank * a["count"] * es
+                    else:
+                        buf[:len(a["input"])] = inp
+                        send_ptr = recv_ptr = buf.data_ptr()
+                    out_view = lambda: buf
+                else:
+                    out = torch.full((a["out_bytes"],), 0xA5, dtype=torch.uint8, device="cuda")
+                    send_ptr, recv_ptr = inp.data_ptr(), out.data_ptr()
+                    out_view = lambda: out
+                op = a["op"]
+                user_op = None
+                if a.get("premul") is not None:
+                    user_op = comm.create_premul_sum(a["premul"], a["dtype"])
+                    op = user_op
+                torch.cuda.synchronize()
+                with torch.cuda.stream(stream):
+                    for _ in range(a.get("iters", 1)):
+                        if a["in_place"] and a.get("iters", 1) > 1:
+                            raise ValueError("in-place with iters>1 would re-reduce its own output")
+                        if a["coll"] == COLL_ALLREDUCE:
+                            comm.all_reduce(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
+                        elif a["coll"] == COLL_REDUCESCATTER:
+                            comm.reduce_scatter(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
+                        else:
+                            comm.all_gather(send_ptr, recv_ptr, a["count"], a["dtype"], stream)
+                stream.synchronize()
+                if user_op is not None:
+                    comm.destroy_op(user_op)
+                err = comm.async_error()
+                res = out_view().cpu().numpy()
+                if a["in_place"]:
+                    if a["coll"] == COLL_REDUCESCATTER:
+                        off = rank * a["count"] * es
+                        res = res[off:off + a["out_bytes"]]
+                    else:
+                        res = res[:a["out_bytes"]]
+                conn.send(("ok", (err, res.tobytes())))
+            elif cmd == "plan":
+                conn.send(("ok", comm.plan_info(*args)))
+            elif cmd == "destroy":
+                if comm is not None:
+                    comm.destroy()
+                    comm = None
+                conn.send(("ok", None))
+            else:
+                conn.send(("err", f"unknown command {cmd}"))
+    except Exception:  # noqa: BLE001 - report everything to the parent
+        try:
+            conn.send(("err", traceback.format_exc()))
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class TestBed:
+    """nranks child processes, rank r on devices[r % len(devices)]."""
+
+    __test__ = False
+
+    def __init__(self, nranks, devices=(0,), env=None, timeout=120):
+        self.nranks = nranks
+        self.timeout = timeout
+        ctx = mp.get_context("spawn")
+        base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "10000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60"}
+        base_env.update(env or {})
+        self.conns, self.procs = [], []
+        for r in range(nranks):
+            parent, child = ctx.Pipe()
+            p = ctx.Process(target=_child, args=(r, nranks, devices[r % len(devices)], child, base_env), daemon=True)
+            p.start()
+            self.conns.append(parent)
+            self.procs.append(p)
+        self.inited = False
+
+    def _recv(self, r):
+        if not self.conns[r].poll(self.timeout):
+            raise TimeoutError(f"rank {r} did not answer within {self.timeout}s")
+        status, val = self.conns[r].recv()
+        if status != "ok":
+            raise RuntimeError(f"rank {r} failed:\n{val}")
+        return val
+
+    def _all(self, cmd, args_per_rank):
+        for r in range(self.nranks):
+            self.conns[r].send((cmd, args_per_rank[r]))
+        return [self._recv(r) for r in range(self.nranks)]
+
+    def init_comms(self, env=None):
+        """(Re)create the communicators; `env` entries are set (None: unset) in every child first."""
+        self.destroy_comms()
+        self.conns[0].send(("uid", None))
+        uid = self._recv(0)
+        info = self._all("init", [(uid, env or {})] * self.nranks)
+        for r, (count, rank, _dev) in enumerate(info):
+            assert count == self.nranks and rank == r
+        self.inited = True
+        return info
+
+    def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1):
+        """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
+        if not self.inited:
+            self.init_comms()
+        args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
+                     out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters)
+                for r in range(self.nranks)]
+        res = self._all("coll", args)
+        for r, (err, _) in enumerate(res):
+            assert err == 0, f"rank {r}: asynchronous error {err}"
+        return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
+
+    def plan(self, coll, count, dtype):
+        self.conns[0].send(("plan", (coll, count, dtype)))
+        return self._recv(0)
+
+    def destroy_comms(self):
+        if self.inited:
+            self._all("destroy", [None] * self.nranks)
+            self.inited = False
+
+    def close(self):
+        try:
+            self.destroy_comms()
+        except Exception:  # noqa: BLE001
+            pass
+        for c in self.conns:
+            try:
+                c.send(("stop", None))
+            except Exception:  # noqa: BLE001
+                pass
+        for p in self.procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
