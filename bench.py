@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ncclAllReduce, sum, fp32, 1 GiB device-resident bucket.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; a step is one ncclAllReduce (through librccl_amd.so's C ABI) over one
+synthetic random bucket already resident in HBM.  Rank 0 prints one JSON line:
+  value      bus bandwidth in GB/s, (S/t) * 2(n-1)/n  (n = 1: the factor is 0, so the copy's
+             algorithm bandwidth S/t is reported instead — src/device/onerank.cu is a copy)
+  roofline   the dominant kernel's algorithmic bytes per launch / its average duration
+             (HIP events on the launch stream) against the bound that applies:
+             n = 1: HBM, 2*S bytes per launch, peak 8000 GB/s;
+             n > 1: xGMI, 2(n-1)/n*S bytes leave each GPU per launch, peak (n-1) links x 153 GB/s
+  cpu_baseline  rank 0, n = 1 only: the oracle's OpenMP element-wise sum over the same bucket on
+             the box's host cores (a reported baseline, not a target)
+
+torch is used for device memory, streams, events and the gloo rendezvous only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak
+XGMI_LINK_GBPS = 153.0        # per xGMI link
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bytes", type=int, default=1 << 30, help="bucket size in bytes (default 1 GiB)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--coll", default="allreduce", choices=["allreduce", "reducescatter", "allgather"])
+    ap.add_argument("--in-place", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import rccl_amd as ra
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    n = world
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py needs a GPU")
+    dev = local_rank % ndev
+    torch.cuda.set_device(dev)
+
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=n)
+
+    def barrier():
+        if n > 1:
+            dist.barrier()
+
+    dt_code = {"fp32": ra.ncclFloat32, "bf16": ra.ncclBfloat16, "fp16": ra.ncclFloat16}[args.dtype]
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
+    es = ra.TYPE_SIZE[dt_code]
+    S = args.bytes                                   # bytes per rank (all-reduce) / per rank block
+    count = S // es
+
+    # communicator: unique id from rank 0 over gloo (what ncclGetUniqueId is for)
+    if n > 1:
+        uid = [ra.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = ra.Communicator.init_rank(n, uid[0], rank)
+    else:
+        comm = ra.Communicator.init_all(1, [dev])[0]
+
+    # synthetic random bucket, seed 0x5EED0000 + rank, uniform [-1, 1)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(0x5EED0000 + rank)
+    if args.coll == "allreduce":
+        in_elems, out_elems = count, count
+    elif args.coll == "reducescatter":
+        in_elems, out_elems = count * n, count
+    else:
+        in_elems, out_elems = count, count * n
+    sendbuf = (torch.rand(in_elems, device="cuda", generator=gen, dtype=torch.float32) * 2 - 1).to(tdt)
+    recvbuf = sendbuf if (args.in_place and args.coll == "allreduce") else torch.zeros(out_elems, device="cuda", dtype=tdt)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        if args.coll == "allreduce":
+            comm.all_reduce(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
+        elif args.coll == "reducescatter":
+            comm.reduce_scatter(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
+        else:
+            comm.all_gather(sendbuf, recvbuf, count, dt_code, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    wall = t1 - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration on the launch stream
+    if comm.async_error() != 0:
+        sys.exit(f"rank {rank}: the communicator reported an asynchronous error")
+
+    if n > 1:
+        t = torch.tensor([wall, kern_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_ms = float(t[0]), float(t[1])
+
+    # correctness spot check on the first elements (all-reduce): gather every rank's head over gloo
+    verified = None
+    if args.coll == "allreduce" and not args.in_place and args.dtype == "fp32":
+        import oracle as orc
+        head = sendbuf[:65536].float().cpu().numpy()
+        if n > 1:
+            heads = [None] * n
+            dist.all_gather_object(heads, head)
+        else:
+            heads = [head]
+        want = orc.host_fold(orc.F32, orc.SUM, heads)
+        got = recvbuf[:65536].float().cpu().numpy()
+        verified = bool(np.array_equal(got, want))
+
+    per_step = wall / args.steps
+    if args.coll == "allreduce":
+        algbw = S / per_step / 1e9
+        factor = 2.0 * (n - 1) / n
+        link_bytes = factor * S
+    else:
+        total = S * n
+        algbw = total / per_step / 1e9
+        factor = (n - 1) / n
+        link_bytes = (n - 1) * S
+    busbw = algbw * factor if n > 1 else algbw
+
+    if n == 1:
+        bound, peak = "hbm", HBM_PEAK_GBPS
+        alg_bytes = 2.0 * S                            # read the bucket once, write it once
+    else:
+        bound, peak = "xgmi", (n - 1) * XGMI_LINK_GBPS
+        alg_bytes = link_bytes                         # bytes that leave each GPU per launch
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                traffic = json.load(f).get(f"{args.coll}_{args.dtype}_{S}_n{n}")
+        except (OSError, ValueError):
+            traffic = None
+
+    line = {
+        "metric": "AllReduce bus-bandwidth GB/s, 1 GiB fp32 sum" if args.coll == "allreduce" else f"{args.coll} bus-bandwidth GB/s",
+        "value": round(busbw, 3), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(per_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
+        "config": {"workload": f"nccl{'AllReduce' if args.coll == 'allreduce' else args.coll} sum {args.dtype} "
+                               f"{S} B per rank, out-of-place, device-resident random bucket"
+                               + ("" if n > 1 else " (1 rank: the reference path is a device copy; value is its S/t)"),
+                   "ranks": n, "ranks_per_gpu": (n + ndev - 1) // ndev, "algbw_GBps": round(algbw, 3),
+                   "plan": comm.plan_info(0 if args.coll == "allreduce" else 1 if args.coll == "reducescatter" else 2,
+                                          count, dt_code) if n > 1 else {"algo": "local copy"}},
+        "verified_against_oracle": verified,
+        "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    if n == 1 and rank == 0 and not args.no_cpu_baseline and args.coll == "allreduce" and args.dtype == "fp32":
+        import oracle as orc
+        host_in = sendbuf.cpu().numpy()
+        host_out = np.empty_like(host_in)
+        orc.omp_sum_f32([host_in], host_out)               # page in
+        reps, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds and reps < 50:
+            c0 = time.perf_counter()
+            orc.omp_sum_f32([host_in], host_out)
+            t_cpu += time.perf_counter() - c0
+            reps += 1
+        cpu_gbps = S * reps / t_cpu / 1e9
+        # the same fold over 8 host buckets of 1/8 the size (what an 8-rank reduce costs per output byte)
+        parts = [host_in[i * (count // 8):(i + 1) * (count // 8)] for i in range(8)]
+        c0 = time.perf_counter()
+        orc.omp_sum_f32(parts, host_out[:count // 8])
+        c8 = time.perf_counter() - c0
+        line["cpu_baseline"] = {"value": round(cpu_gbps, 3), "unit": "GB/s", "cores": orc.omp_threads(), "kind": "port",
+                                "sample": f"{reps} passes of the OpenMP element-wise sum (oracle/oracle.c) over the same "
+                                          f"{S} B fp32 bucket, 1 rank => S/t of a host copy; 8-way sum of 8 x {S // 8} B "
+                                          f"buckets ran at {round(S / 8 / c8 / 1e9, 3)} GB/s of output",
+                                "host_cpus": os.cpu_count()}
+
+    comm.destroy()
+    if n > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
