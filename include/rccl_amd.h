@@ -168,6 +168,19 @@ ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll,
                              size_t count, ncclDataType_t datatype, int* algo, int* proto,
                              int* nChannels, size_t* chunkElems);
 
+/* The same plan computed from explicit settings, without a communicator or a GPU (host logic only):
+ * algo < 0 = default choice; maxChannels / slotBytes / minChunkBytes as a communicator would hold
+ * them (defaults 16, 524288, 32768).  grid = workgroups the launch would use. */
+ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo,
+                                  int maxChannels, size_t slotBytes, size_t minChunkBytes, int* algoOut,
+                                  int* nChannels, size_t* chunkElems, size_t* lastChunkElems, int* grid);
+
+/* Rendezvous check without a GPU: joins the endpoint named by `id` as `rank` of `nranks`, all-gathers
+ * `bytes` bytes per rank into `all`, and leaves.  It is the exchange ncclCommInitRank performs for the
+ * window handles (role of bootstrapAllGather, src/bootstrap.cc), callable from CPU-only tests. */
+ncclResult_t rcclAmdBootstrapAllGather(const ncclUniqueId* id, int rank, int nranks, const void* mine,
+                                       void* all, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,28 @@ RA_API ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll, size_t count, ncc
   if (chunkElems) *chunkElems = p.chunkElems;
   return ncclSuccess;
 }
+
+RA_API ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo, int maxChannels,
+                                         size_t slotBytes, size_t minChunkBytes, int* algoOut, int* nChannels,
+                                         size_t* chunkElems, size_t* lastChunkElems, int* grid) {
+  if (coll < 0 || coll > RA_COLL_ALLGATHER) return ncclInvalidArgument;
+  RaPlan p;
+  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, maxChannels, slotBytes, minChunkBytes, 512, &p));
+  if (algoOut) *algoOut = p.algo;
+  if (nChannels) *nChannels = p.nChannels;
+  if (chunkElems) *chunkElems = p.chunkElems;
+  if (lastChunkElems) *lastChunkElems = p.lastChunkElems;
+  if (grid) *grid = p.grid;
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t rcclAmdBootstrapAllGather(const ncclUniqueId* id, int rank, int nranks, const void* mine, void* all,
+                                              size_t bytes) {
+  if (!id || !mine || !all || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+  RaBootstrap b;
+  ncclResult_t r = b.connect(*id, rank, nranks);
+  if (r == ncclSuccess) r = b.allGather(mine, all, bytes);
+  if (r == ncclSuccess) r = b.barrier();
+  b.close();
+  return r;
+}

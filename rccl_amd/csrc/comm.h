@@ -93,6 +93,8 @@ struct RaCollArgs {
   hipStream_t stream;
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
+ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
+                       size_t minChunkBytes, int blockThreads, RaPlan* plan);
 ncclResult_t raEnqueue(const RaCollArgs& a);
 ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();

@@ -189,19 +189,20 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
 // all-pairs schedule is the default wherever every rank has its own link to every other
 // (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
 // and NCCL_ALGO selects the ring or chain schedules.
-ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
+ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
+                       size_t minChunkBytes, int blockThreads, RaPlan* p) {
   const size_t es = raTypeSize(dtype);
-  if (es == 0) return ncclInvalidArgument;
-  const int n = c->nRanks;
-  int algo = c->algoEnv >= 0 ? c->algoEnv : RA_ALGO_DIRECT;
+  if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
+  int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
   if (algo == RA_ALGO_TREE && coll != RA_COLL_ALLREDUCE) algo = RA_ALGO_RING;   // no chain schedule for these two
   if (algo == RA_ALGO_DIRECT && n > RA_MAX_SRCS) algo = RA_ALGO_RING;
   p->algo = algo;
   p->proto = 0;
-  p->block = c->blockThreads;
+  p->block = blockThreads;
   const size_t unit = 16 / es;                                  // elements per 16-byte pack
-  const size_t maxChunk = (size_t)c->lay.slotBytes / es;        // one FIFO slot
-  const size_t minChunk = alignUp(c->minChunkBytes / es, unit);
+  const size_t maxChunk = slotBytes / es / unit * unit;         // one FIFO slot
+  size_t minChunk = alignUp(minChunkBytes / es, unit);
+  if (minChunk > maxChunk) minChunk = maxChunk;
   // elements each owner handles in total
   size_t perOwner;
   if (coll == RA_COLL_ALLREDUCE && algo != RA_ALGO_TREE) perOwner = divUp(count, (size_t)n);
@@ -209,15 +210,15 @@ ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan
   // channels: enough that each has at least one minimum chunk
   size_t nCh = divUp(perOwner, minChunk);
   if (nCh < 1) nCh = 1;
-  if (nCh > (size_t)c->maxChannels) nCh = (size_t)c->maxChannels;
+  if (nCh > (size_t)maxChannels) nCh = (size_t)maxChannels;
   // chunk: about four rounds per channel when the data allows, never above one slot
   size_t chunk = alignUp(divUp(perOwner, nCh * 4), unit);
   if (chunk < minChunk) chunk = minChunk;
-  if (chunk > maxChunk) chunk = maxChunk / unit * unit;
+  if (chunk > maxChunk) chunk = maxChunk;
   p->nChannels = (int)nCh;
   p->chunkElems = chunk;
   p->lastChunkElems = chunk;
-  if (coll == RA_COLL_ALLREDUCE && algo != RA_ALGO_TREE) {
+  if (coll == RA_COLL_ALLREDUCE && algo != RA_ALGO_TREE && count > 0) {
     const size_t roundElems = chunk * (size_t)n;
     const size_t nRounds = divUp(count, roundElems);
     const size_t rem = count - (nRounds - 1) * roundElems;
@@ -227,6 +228,11 @@ ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan
   }
   p->grid = gridFor(coll, algo, p->nChannels);
   return ncclSuccess;
+}
+
+ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
+  return raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
+                   c->blockThreads, p);
 }
 
 int raGroupDepth() { return tGroupDepth; }

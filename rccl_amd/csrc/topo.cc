@@ -130,7 +130,9 @@ int raTopoRings(int n, const int* adj, int maxRings, std::vector<std::vector<int
         std::vector<int> rot;
         rot.push_back(0);
         for (int i = 0; i + 1 < n; i++) rot.push_back(rev[i]);
-        rings.push_back(rot);
+        bool present = false;                          // a set already closed under reversal stays as it is
+        for (const auto& f : found) present = present || f == rot;
+        if (!present) rings.push_back(rot);
       }
   } else if (exactCover(n, adj, 2, found)) {
     rings = found;

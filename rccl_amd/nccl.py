@@ -33,6 +33,7 @@ EXPORTS = [
     "ncclRedOpCreatePreMulSum", "ncclRedOpDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather",
     "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
     "ncclCommSplit", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
+    "rcclAmdPlanForConfig", "rcclAmdBootstrapAllGather",
 ]
 
 
@@ -99,6 +100,9 @@ def lib():
         L.rcclAmdTopoParseXml.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.rcclAmdPlanInfo.argtypes = [vp, ci, sz, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                       ctypes.POINTER(sz)]
+        L.rcclAmdPlanForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                           ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
+        L.rcclAmdBootstrapAllGather.argtypes = [ctypes.POINTER(ncclUniqueId), ci, ci, vp, vp, sz]
         _lib = L
     return _lib
 
@@ -263,3 +267,23 @@ def topo_parse_xml(text, max_gpus=16):
     _check(lib().rcclAmdTopoParseXml(text.encode(), max_gpus, adj, ctypes.byref(n)), "rcclAmdTopoParseXml")
     k = n.value
     return [[adj[i * k + j] for j in range(k)] for i in range(k)]
+
+
+def plan_for_config(nranks, coll, count, datatype, algo=-1, max_channels=16, slot_bytes=512 << 10, min_chunk_bytes=32 << 10):
+    """rcclAmdPlanForConfig: the planner's decision for explicit settings (no GPU needed)."""
+    a, c, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    ch, last = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(lib().rcclAmdPlanForConfig(nranks, coll, count, datatype, algo, max_channels, slot_bytes, min_chunk_bytes,
+                                      ctypes.byref(a), ctypes.byref(c), ctypes.byref(ch), ctypes.byref(last),
+                                      ctypes.byref(g)), "rcclAmdPlanForConfig")
+    return {"algo": a.value, "nChannels": c.value, "chunkElems": ch.value, "lastChunkElems": last.value, "grid": g.value}
+
+
+def bootstrap_all_gather(unique_id, rank, nranks, mine):
+    """rcclAmdBootstrapAllGather: every rank's `mine` (bytes), in rank order."""
+    uid = ncclUniqueId()
+    ctypes.memmove(ctypes.byref(uid), unique_id, NCCL_UNIQUE_ID_BYTES)
+    out = ctypes.create_string_buffer(len(mine) * nranks)
+    _check(lib().rcclAmdBootstrapAllGather(ctypes.byref(uid), rank, nranks, mine, out, len(mine)),
+           "rcclAmdBootstrapAllGather")
+    return [out.raw[i * len(mine):(i + 1) * len(mine)] for i in range(nranks)]

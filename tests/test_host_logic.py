@@ -1,0 +1,90 @@
+"""Host logic on CPU: the planner's geometry, the expected-value builder that mirrors it, and the
+multi-process rendezvous (world_size 2 over gloo + the library's own bootstrap)."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+import expected as ex
+import oracle as orc
+import rccl_amd as ra
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+@pytest.mark.parametrize("dt", [ra.ncclFloat32, ra.ncclBfloat16, ra.ncclUint8, ra.ncclFloat64])
+@pytest.mark.parametrize("count", [1, 384, 1250, 393216, 5 * 1024 * 1024 + 123, 1 << 28])
+def test_allreduce_plan_geometry(n, dt, count):
+    es = ra.TYPE_SIZE[dt]
+    p = ra.plan_for_config(n, 0, count, dt)
+    unit = 16 // es
+    assert p["algo"] == 0 and 1 <= p["nChannels"] <= 16
+    assert p["chunkElems"] % unit == 0 and p["chunkElems"] * es <= 512 << 10        # one FIFO slot
+    assert p["grid"] == 3 * p["nChannels"] <= 256                                    # all workgroups resident
+    # every element belongs to exactly one (round, piece)
+    chunk, last = p["chunkElems"], p["lastChunkElems"]
+    nrounds, last_expected = ex._last_chunk(count, n, chunk, {4: orc.F32, 2: orc.BF16, 1: orc.U8, 8: orc.F64}[es])
+    assert last == last_expected and last % unit == 0
+    covered = (nrounds - 1) * n * chunk + min(count - (nrounds - 1) * n * chunk, n * last)
+    assert covered == count
+
+
+def test_plan_algorithm_overrides():
+    assert ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=1)["grid"] == ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=1)["nChannels"]
+    t = ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=2)
+    assert t["algo"] == 2 and t["grid"] == 2 * t["nChannels"]
+    # tree is an all-reduce schedule only: the other two fall back to the ring (as the reference does)
+    assert ra.plan_for_config(8, 1, 1 << 20, ra.ncclFloat32, algo=2)["algo"] == 1
+    # more than 8 ranks cannot use the 8-source all-pairs fold
+    assert ra.plan_for_config(16, 0, 1 << 20, ra.ncclFloat32)["algo"] == 1
+
+
+def test_expected_builder_orders():
+    """tests/expected.py: direct == rank-order fold; ring/tree differ from it only within tolerance."""
+    n, count = 4, 70001
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    host = orc.host_fold(orc.F32, orc.SUM, ins)
+    rings = ra.topo_rings(n, [[int(i != j) for j in range(n)] for i in range(n)])
+    for algo in (0, 1, 2):
+        p = ra.plan_for_config(n, 0, count, ra.ncclFloat32, algo=algo)
+        want = ex.allreduce(orc.F32, orc.SUM, ins, p, rings)
+        assert orc.first_mismatch(orc.F32, want, host) == -1
+        if algo == 0:
+            assert np.array_equal(want, host)
+    i32 = [orc.fill_pattern(orc.I32, count, r) for r in range(n)]
+    for algo in (0, 1, 2):
+        p = ra.plan_for_config(n, 0, count, ra.ncclInt32, algo=algo)
+        assert np.array_equal(ex.allreduce(orc.I32, orc.PROD, i32, p, rings), orc.host_fold(orc.I32, orc.PROD, i32))
+
+
+def _gloo_rank(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # what bench.py does: rank 0 creates the id, gloo carries it to the others
+        uid = [ra.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        mine = bytes([rank + 1]) * 64
+        got = ra.bootstrap_all_gather(uid[0], rank, world, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, got))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rendezvous_world_size_n_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world + (os.getpid() % 200)
+    ps = [ctx.Process(target=_gloo_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=30)
+    for r in range(world):
+        assert res[r] == [bytes([k + 1]) * 64 for k in range(world)], res[r]
