@@ -66,6 +66,11 @@ def main():
         sys.exit("bench.py needs a GPU")
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
+    per_gpu = (n + ndev - 1) // ndev
+    if per_gpu > 1:
+        # Loop-back mode (several ranks on one GPU, for kernel work on a one-GPU box): the ranks share
+        # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
+        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // per_gpu)))
 
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -171,10 +171,9 @@ RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int ns
   if (datatype < 0 || datatype > ncclBfloat16 || op < 0 || op > ncclMin) { RA_WARN("rcclAmdReduceCopy: unsupported type/op"); return ncclInvalidArgument; }
   if (count == 0) return ncclSuccess;
   const size_t bytes = count * raTypeSize(datatype);
-  size_t grid = (bytes + 256 * 64 - 1) / (256 * 64);
-  if (grid > 2048) grid = 2048;
+  const int grid = raLocalGrid(bytes, nsrc);
   static const int devOps[] = {RA_OP_SUM, RA_OP_PROD, RA_OP_MAX, RA_OP_MIN};
-  hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, count, datatype, devOps[op], (int)grid, stream);
+  hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, count, datatype, devOps[op], grid, stream);
   if (e != hipSuccess) { RA_WARN("rcclAmdReduceCopy: launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
   return ncclSuccess;
 }

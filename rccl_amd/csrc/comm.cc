@@ -43,15 +43,20 @@ struct DeviceGuard {
 void readTunables(ncclComm* c) {
   // NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS as in src/graph/connect.cc:521-545; the native
   // knob is RCCL_AMD_NCHANNELS.
+  // Default: 8 channels per xGMI link in use, between 16 and 56 (56 = 8 x 7 links at 8 ranks; the
+  // reference also ends up with 56 channels on an 8-GPU all-to-all node, src/graph/connect.cc:638-660).
+  long dflt = 8L * (c->nRanks - 1);
+  if (dflt < 16) dflt = 16;
+  if (dflt > 56) dflt = 56;
   long ch = envLong("RCCL_AMD_NCHANNELS", -1);
-  if (ch < 0) ch = envLong("NCCL_MAX_NCHANNELS", 16);
+  if (ch < 0) ch = envLong("NCCL_MAX_NCHANNELS", dflt);
   long mn = envLong("NCCL_MIN_NCHANNELS", 1);
   if (ch < mn) ch = mn;
   if (ch < 1) ch = 1;
   if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
   c->maxChannels = (int)ch;
   long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 512));
-  c->blockThreads = nt <= 256 ? 256 : 512;
+  c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
   c->algoEnv = -1;
@@ -75,7 +80,7 @@ void makeLayout(ncclComm* c) {
   long slotBytes = envLong("RCCL_AMD_SLOT_BYTES", -1);
   if (slotBytes <= 0) {
     long buff = envLong("NCCL_BUFFSIZE", -1);      // whole FIFO, as in src/init.cc:837-875
-    slotBytes = buff > 0 ? buff / slots : (512 << 10);
+    slotBytes = buff > 0 ? buff / slots : (256 << 10);
   }
   if (slotBytes < 4096) slotBytes = 4096;
   l.slotBytes = (uint32_t)alignUp((size_t)slotBytes, 4096);
@@ -148,6 +153,7 @@ ncclResult_t buildDevComm(ncclComm* c) {
   long ms = envLong("RCCL_AMD_SPIN_TIMEOUT_MS", 120000);
   if (ms < 1) ms = 1;
   h.timeoutTicks = (uint64_t)ms * 100000ull;
+  h.tuneFlags = (uint32_t)envLong("RCCL_AMD_TUNE_FLAGS", 0);
   h.nRings = c->nRings;
   memcpy(h.ringRanks, c->ringRanks, sizeof h.ringRanks);
   RA_HIP(hipMalloc((void**)&c->devComm, sizeof h));

@@ -68,6 +68,7 @@ struct RaDevComm {
   uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
+  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = add a release fence before posting, 2 = no acquire fence
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];

@@ -140,9 +140,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
     if (a.send == a.recv && !scale) return ncclSuccess;
     const void* srcs[1] = {a.send};
     const size_t bytes = a.count * es;
-    int grid = (int)divUp(bytes, 256 * 64);
-    if (grid > 2048) grid = 2048;
-    if (grid < 1) grid = 1;
+    int grid = raLocalGrid(bytes, 1);
     hipError_t e = scale ? raLaunchLocal(a.recv, srcs, 1, 0, false, arg, a.count, a.dtype, RA_OP_PREMULSUM, grid, a.stream)
                          : raLaunchLocal(a.recv, srcs, 1, -1, false, 0, bytes, ncclInt8, RA_OP_SUM, grid, a.stream);
     if (e != hipSuccess) { RA_WARN("local kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }

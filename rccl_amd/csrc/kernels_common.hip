@@ -2,7 +2,7 @@
 // per-type translation units built from kernels_dtype.hip.
 #include "kernels_impl.h"
 
-__global__ __launch_bounds__(512) void raGatherKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+__global__ __launch_bounds__(1024) void raGatherKernel(const RaDevComm* __restrict__ comm, RaWork w) {
   __shared__ ChanShared sh;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;

@@ -40,7 +40,7 @@ static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int b
 }
 template <int OP>
 static hipError_t localOp(const RcArgs& a, size_t nelem, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(256), 0, s, a, nelem);
+  hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(RA_LOCAL_THREADS), 0, s, a, nelem);
   return hipGetLastError();
 }
 

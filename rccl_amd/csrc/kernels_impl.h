@@ -129,8 +129,23 @@ template <typename T> __device__ __forceinline__ u32x4 packPost(u32x4 a, uint64_
   return x.v;
 }
 
-__device__ __forceinline__ u32x4 ldPack(const u32x4* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void stPack(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+// Global-address-space accesses (never flat): nontemporal 16-byte loads and stores.
+typedef __attribute__((address_space(1))) const u32x4 gc_u32x4;
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+__device__ __forceinline__ u32x4 ldPack(const u32x4* p) { return __builtin_nontemporal_load((gc_u32x4*)(uint64_t)p); }
+__device__ __forceinline__ void stPack(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, (g_u32x4*)(uint64_t)p); }
+// scalar 64-bit base + 32-bit per-lane byte offset
+__device__ __forceinline__ u32x4 ldAt(uint64_t base, uint32_t off) { return __builtin_nontemporal_load((gc_u32x4*)(base + off)); }
+__device__ __forceinline__ void stAt(uint64_t base, uint32_t off, u32x4 v) { __builtin_nontemporal_store(v, (g_u32x4*)(base + off)); }
+// Store into a peer's window: system-scope write-through (sc0 sc1), so the bytes are at their
+// destination once the wave's vmcnt drains and no cache write-back is needed before the flag.
+// hipcc does not count this store; every step ends with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void stSysAt(uint64_t base, uint32_t off, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void stSys(u32x4* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+}
 
 // ------------------------------------------------------------------ reduce-copy
 // dst[k][i] = post( pre?(src[0][i]) (op) src[1][i] (op) ... ), folded left to right.
@@ -141,35 +156,56 @@ struct RcArgs {
   char* dst[RA_MAX_SRCS];
   int ns, nd, preIdx;
   bool post;
+  uint32_t sysMask = 0;  // bit k set: dst[k] is a peer's window slot (system-scope write-through store)
   uint64_t opArg;
 };
+
+// Values that are the same in every lane but reach us through memory or a call (so the
+// compiler cannot know it) are moved to scalar registers: addresses then take the
+// scalar-base + 32-bit lane-offset form and cost one VGPR per pack instead of two per stream.
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ const char* uniformPtr(const char* p) { return (const char*)uniform64((uint64_t)p); }
+__device__ __forceinline__ char* uniformPtr(char* p) { return (char*)uniform64((uint64_t)p); }
 
 // Packs [first, npacks) in tiles of nthr*U packs; tile t starts at first + t*tileStep.
 // NS > 0: the source count is a compile-time constant and all NS*U loads are issued
 // before the first use, so one wave keeps NS*U KiB in flight.  NS == 0: any count.
 template <typename T, int OP, int NS, int U>
-__device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacks, size_t first, size_t tileStep, int tid, int nthr) {
+__device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t firstIn, size_t tileStepIn, int tid, int nthr) {
   constexpr int NSA = NS > 0 ? NS : 1;
-  const u32x4* s[NSA];
+  const size_t npacks = uniform64(npacksIn), first = uniform64(firstIn), tileStep = uniform64(tileStepIn);
+  const int ns = __builtin_amdgcn_readfirstlane(a.ns), nd = __builtin_amdgcn_readfirstlane(a.nd);
+  const int preIdx = __builtin_amdgcn_readfirstlane(a.preIdx);
+  const uint64_t opArg = uniform64(a.opArg);
+  const bool post = __builtin_amdgcn_readfirstlane((int)a.post) != 0;
+  const uint32_t sysMask = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sysMask);
+  const char* s[NSA];
 #pragma unroll
-  for (int j = 0; j < NSA; j++) s[j] = (const u32x4*)a.src[j];
-  const size_t tile = (size_t)nthr * U;
+  for (int j = 0; j < NSA; j++) s[j] = uniformPtr(a.src[j]);
+  const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
+  const uint32_t lane16 = (uint32_t)tid * 16u;          // this thread's byte offset inside a row of nthr packs
+  const uint32_t row = nthrU * 16u;                     // bytes between a thread's consecutive packs
+  const size_t tile = (size_t)nthrU * U;
   size_t base = first;
   for (; base + tile <= npacks; base += tileStep) {
-    const size_t i0 = base + tid;
+    const size_t b16 = base * 16;                       // uniform byte offset of this tile
     u32x4 acc[U];
     if (NS > 0) {
       u32x4 v[NSA][U];
 #pragma unroll
       for (int j = 0; j < NSA; j++)
 #pragma unroll
-        for (int u = 0; u < U; u++) v[j][u] = ldPack(s[j] + i0 + (size_t)u * nthr);
+        for (int u = 0; u < U; u++) v[j][u] = ldAt((uint64_t)s[j] + b16, lane16 + (uint32_t)u * row);
       if (OP == RA_OP_PREMULSUM) {
 #pragma unroll
         for (int j = 0; j < NSA; j++)
-          if (j == a.preIdx) {
+          if (j == preIdx) {
 #pragma unroll
-            for (int u = 0; u < U; u++) v[j][u] = packPre<T>(v[j][u], a.opArg);
+            for (int u = 0; u < U; u++) v[j][u] = packPre<T>(v[j][u], opArg);
           }
       }
 #pragma unroll
@@ -181,46 +217,66 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacks, size_t f
     } else {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        acc[u] = ldPack(s[0] + i0 + (size_t)u * nthr);
-        if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc[u] = packPre<T>(acc[u], a.opArg);
+        acc[u] = ldAt((uint64_t)s[0] + b16, lane16 + (uint32_t)u * row);
+        if (OP == RA_OP_PREMULSUM && preIdx == 0) acc[u] = packPre<T>(acc[u], opArg);
       }
-      for (int j = 1; j < a.ns; j++) {
-        const u32x4* sj = (const u32x4*)a.src[j];
+      for (int j = 1; j < ns; j++) {
+        const char* sj = uniformPtr(a.src[j]) + b16;
         u32x4 t[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) t[u] = ldPack(sj + i0 + (size_t)u * nthr);
+        for (int u = 0; u < U; u++) t[u] = ldAt((uint64_t)sj, lane16 + (uint32_t)u * row);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          if (OP == RA_OP_PREMULSUM && a.preIdx == j) t[u] = packPre<T>(t[u], a.opArg);
+          if (OP == RA_OP_PREMULSUM && preIdx == j) t[u] = packPre<T>(t[u], opArg);
           acc[u] = packRed<T, OP>(acc[u], t[u]);
         }
       }
     }
-    if (OP == RA_OP_SUMPOSTDIV && a.post) {
+    if (OP == RA_OP_SUMPOSTDIV && post) {
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], a.opArg);
+      for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], opArg);
     }
-    for (int k = 0; k < a.nd; k++) {
-      u32x4* d = (u32x4*)a.dst[k];
+    for (int k = 0; k < nd; k++) {
+      char* d = uniformPtr(a.dst[k]) + b16;
+      if (sysMask >> k & 1) {
 #pragma unroll
-      for (int u = 0; u < U; u++) stPack(d + i0 + (size_t)u * nthr, acc[u]);
+        for (int u = 0; u < U; u++) stSysAt((uint64_t)d, lane16 + (uint32_t)u * row, acc[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) stAt((uint64_t)d, lane16 + (uint32_t)u * row, acc[u]);
+      }
     }
   }
   // Ragged end: the one tile that is not full, one pack per thread per pass.  Only the
   // workgroup whose walk reaches it handles it.
   if (base < npacks) {
-    for (size_t i = base + tid; i < npacks; i += nthr) {
-      u32x4 acc = ldPack((const u32x4*)a.src[0] + i);
-      if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc = packPre<T>(acc, a.opArg);
-      for (int j = 1; j < a.ns; j++) {
-        u32x4 t = ldPack((const u32x4*)a.src[j] + i);
-        if (OP == RA_OP_PREMULSUM && a.preIdx == j) t = packPre<T>(t, a.opArg);
+    for (size_t i = base + tid; i < npacks; i += nthrU) {
+      u32x4 acc = ldPack((const u32x4*)uniformPtr(a.src[0]) + i);
+      if (OP == RA_OP_PREMULSUM && preIdx == 0) acc = packPre<T>(acc, opArg);
+      for (int j = 1; j < ns; j++) {
+        u32x4 t = ldPack((const u32x4*)uniformPtr(a.src[j]) + i);
+        if (OP == RA_OP_PREMULSUM && preIdx == j) t = packPre<T>(t, opArg);
         acc = packRed<T, OP>(acc, t);
       }
-      if (OP == RA_OP_SUMPOSTDIV && a.post) acc = packPost<T>(acc, a.opArg);
-      for (int k = 0; k < a.nd; k++) stPack((u32x4*)a.dst[k] + i, acc);
+      if (OP == RA_OP_SUMPOSTDIV && post) acc = packPost<T>(acc, opArg);
+      for (int k = 0; k < nd; k++) {
+        if (sysMask >> k & 1) stSys((u32x4*)uniformPtr(a.dst[k]) + i, acc);
+        else stPack((u32x4*)uniformPtr(a.dst[k]) + i, acc);
+      }
     }
   }
+}
+
+// One element into a peer's window, system-scope write-through (see stSysAt).
+template <typename T> __device__ __forceinline__ void stSysElem(T* p, T v) {
+  if constexpr (sizeof(T) == 1) { union { T t; uint8_t u; } x; x.t = v; const uint32_t w = x.u;
+    asm volatile("global_store_byte %0, %1, off sc0 sc1" : : "v"(p), "v"(w) : "memory"); }
+  else if constexpr (sizeof(T) == 2) { union { T t; uint16_t u; } x; x.t = v; const uint32_t w = x.u;
+    asm volatile("global_store_short %0, %1, off sc0 sc1" : : "v"(p), "v"(w) : "memory"); }
+  else if constexpr (sizeof(T) == 4) { union { T t; uint32_t u; } x; x.t = v;
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(x.u) : "memory"); }
+  else { union { T t; uint64_t u; } x; x.t = v;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(x.u) : "memory"); }
 }
 
 // Elements [first, nelem) one at a time (unaligned pointers, or the sub-pack tail).
@@ -236,7 +292,10 @@ __device__ __forceinline__ void rcElems(const RcArgs& a, size_t nelem, size_t fi
       acc = Elem<T, R>::red(acc, t);
     }
     if (OP == RA_OP_SUMPOSTDIV && a.post) acc = Scale<T>::post(acc, a.opArg);
-    for (int k = 0; k < a.nd; k++) ((T*)a.dst[k])[i] = acc;
+    for (int k = 0; k < a.nd; k++) {
+      if (a.sysMask >> k & 1) stSysElem<T>((T*)a.dst[k] + i, acc);
+      else ((T*)a.dst[k])[i] = acc;
+    }
   }
 }
 
@@ -266,10 +325,11 @@ __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int ti
   if (rcAligned(a)) {
     const size_t npacks = nelem * sizeof(T) / 16;
     switch (a.ns) {
-      case 1: rcCase<T, OP, 1, 4>(a, npacks, tid, nthr, part, nparts); break;
+      // sources x packs per thread = 8 loads (128 B) in flight per thread in every case
+      case 1: rcCase<T, OP, 1, 8>(a, npacks, tid, nthr, part, nparts); break;
       case 2: rcCase<T, OP, 2, 4>(a, npacks, tid, nthr, part, nparts); break;
       case 4: rcCase<T, OP, 4, 2>(a, npacks, tid, nthr, part, nparts); break;
-      case 8: rcCase<T, OP, 8, 2>(a, npacks, tid, nthr, part, nparts); break;
+      case 8: rcCase<T, OP, 8, 1>(a, npacks, tid, nthr, part, nparts); break;
       default: rcCase<T, OP, 0, 2>(a, npacks, tid, nthr, part, nparts); break;
     }
     const size_t done = npacks * (16 / sizeof(T));
@@ -289,7 +349,7 @@ __device__ __noinline__ void rcWG(const RcArgs& a, size_t nelem, int tid, int nt
 static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int tid, int nthr) {
   if (nbytes == 0 || a.nd == 0) return;
   if (rcAligned(a)) {
-    rcCase<int8_t, RA_OP_SUM, 1, 4>(a, nbytes / 16, tid, nthr, 0, 1);
+    rcCase<int8_t, RA_OP_SUM, 1, 8>(a, nbytes / 16, tid, nthr, 0, 1);
     const size_t done = nbytes & ~(size_t)15;
     if (done < nbytes) rcElems<int8_t, RA_OP_SUM>(a, nbytes, done, nthr, tid);
   } else {
@@ -300,7 +360,7 @@ static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int t
 // ------------------------------------------------------------------ local kernels
 // One rank (src/device/onerank.cu) and the exported N-source reduce-copy.
 template <typename T, int OP>
-__global__ __launch_bounds__(256) void raLocalKernel(RcArgs a, size_t nelem) {
+__global__ __launch_bounds__(1024) void raLocalKernel(RcArgs a, size_t nelem) {
   reduceCopy<T, OP>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
 }
 
@@ -395,7 +455,7 @@ struct Ctx {
     if (tid < RA_MAX_RANKS) {
       if (recvMask >> tid & 1) {
         spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        if (!(comm->tuneFlags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       }
     } else if (tid < 2 * RA_MAX_RANKS) {
       const int p = tid - RA_MAX_RANKS;
@@ -411,7 +471,9 @@ struct Ctx {
     drainVmem();       // every wave: its loads have returned and its stores are acknowledged
     __syncthreads();
     if (tid < 64) {
-      if (sendMask) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); drainVmem(); }
+      // Window data went out as system-scope write-through stores and every wave drained them before the
+      // barrier above, so no cache write-back is needed here (tuneFlags bit 0 adds a full release fence back).
+      if (sendMask && (comm->tuneFlags & 1)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); drainVmem(); }
       if (tid < RA_MAX_RANKS) {
         if (recvMask >> tid & 1) {          // slot consumed: credit to the sender (its window)
           const uint64_t s = sh->recvStep[tid][rk] + 1;
@@ -473,11 +535,11 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
-        for (int i = 1; i < n; i++) {
-          const int p = (r + i) % n;
+        for (int i = 0; i < n - 1; i++) {
+          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0);
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         }
       });
@@ -488,7 +550,7 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
         for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
         a.dst[0] = (char*)(out + off);
         int k = 1;
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     } else {
@@ -519,10 +581,10 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
-        for (int i = 1; i < n; i++) {
-          const int p = (r + i) % n;
+        for (int i = 0; i < n - 1; i++) {
+          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0);
+          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         }
       });
@@ -556,7 +618,7 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
         int k = 0;
         char* mine = w.recv + (size_t)r * nbytes + off;
         if (mine != w.send + off) a.dst[k++] = mine;
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
         a.nd = k;
         copyWG(a, nb, cx.tid, cx.nthr);
       });
@@ -603,7 +665,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
     R.piece(g, (rp.ix + n - 1) % n, off, ne);
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0);
+      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: local + received -> next
@@ -612,7 +674,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
         a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = cx.sendSlot(rp.next, 0);
+        a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
@@ -621,7 +683,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
     cx.step(pm, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
       a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0);
+      a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: keep and forward finished pieces
@@ -630,7 +692,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0);
+        a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
         copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
       });
     }
@@ -660,7 +722,7 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
     int blk = rp.order[(rp.ix + n - 1) % n];
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0);
+      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     for (int j = 2; j < n; j++) {
@@ -668,7 +730,7 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
         a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = cx.sendSlot(rp.next, 0);
+        a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
@@ -698,7 +760,7 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
       int k = 0;
       char* mine = w.recv + (size_t)cx.rank * nbytes + off;
       if (mine != w.send + off) a.dst[k++] = mine;
-      a.dst[k++] = cx.sendSlot(rp.next, 0);
+      a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(rp.next, 0);
       a.nd = k;
       copyWG(a, nb, cx.tid, cx.nthr);
     });
@@ -707,7 +769,7 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.dst[1] = cx.sendSlot(rp.next, 0);
+        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
         copyWG(a, nb, cx.tid, cx.nthr);
       });
     }
@@ -743,21 +805,21 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
       if (leaf) {
         cx.step(0, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0);
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0); a.sysMask |= 1u << 0;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       } else if (!root) {
         cx.step(1u << child, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = cx.sendSlot(parent, 0);
+          a.dst[0] = cx.sendSlot(parent, 0); a.sysMask |= 1u << 0;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       } else {
         cx.step(1u << child, 0, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1);
+          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1); a.sysMask |= 1u << 1;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       }
@@ -773,7 +835,7 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
         cx.step(1u << parent, 1, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
           a.src[0] = cx.recvSlot(parent, 1);
-          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1);
+          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1); a.sysMask |= 1u << 1;
           copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       }
@@ -784,7 +846,7 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
 // ------------------------------------------------------------------ the collective kernel
 // grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.
 template <typename T, int OP>
-__global__ __launch_bounds__(512) void raCollKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+__global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict__ comm, RaWork w) {
   __shared__ ChanShared sh;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;

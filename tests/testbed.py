@@ -118,7 +118,10 @@ class TestBed:
         self.nranks = nranks
         self.timeout = timeout
         ctx = mp.get_context("spawn")
-        base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "10000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60"}
+        # Ranks that share a GPU share its 256 CUs: keep ranks x roles x channels workgroups resident.
+        per_gpu = -(-nranks // len(devices))
+        base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "10000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60",
+                    "RCCL_AMD_NCHANNELS": str(max(2, min(16, 64 // per_gpu)))}
         base_env.update(env or {})
         self.conns, self.procs = [], []
         for r in range(nranks):
