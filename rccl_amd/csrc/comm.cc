@@ -55,7 +55,7 @@ void readTunables(ncclComm* c) {
   if (ch < 1) ch = 1;
   if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
   c->maxChannels = (int)ch;
-  long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 512));
+  long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 1024));
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;

@@ -357,6 +357,56 @@ static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int t
   }
 }
 
+// Up to RA_MAX_SRCS independent copies src[j] -> dst[j] of `nbytes` each in ONE pass: every thread
+// has one 16-byte load per pair in flight, so the n-1 pieces a scatter or gather role moves per
+// round share a single load-latency ramp instead of paying it once per piece.
+static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn, int tid, int nthr) {
+  const int np = __builtin_amdgcn_readfirstlane(a.ns);
+  const size_t nbytes = uniform64(nbytesIn);
+  if (nbytes == 0 || np == 0) return;
+  const uint32_t sysMask = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sysMask);
+  uintptr_t m = 0;
+  for (int j = 0; j < np; j++) m |= (uintptr_t)a.src[j] | (uintptr_t)a.dst[j];
+  const bool aligned = (uniform64(m) & 15) == 0;
+  size_t done = 0;
+  if (aligned) {
+    const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
+    const uint32_t lane16 = (uint32_t)tid * 16u;
+    const size_t row = (size_t)nthrU * 16;
+    uint64_t s[RA_MAX_SRCS], d[RA_MAX_SRCS];
+#pragma unroll
+    for (int j = 0; j < RA_MAX_SRCS; j++) {
+      s[j] = uniform64((uint64_t)a.src[j < np ? j : 0]);
+      d[j] = uniform64((uint64_t)a.dst[j < np ? j : 0]);
+    }
+    const size_t full = nbytes / row * row;
+    for (size_t b = 0; b < full; b += row) {
+      u32x4 v[RA_MAX_SRCS];
+#pragma unroll
+      for (int j = 0; j < RA_MAX_SRCS; j++)
+        if (j < np) v[j] = ldAt(s[j] + b, lane16);
+#pragma unroll
+      for (int j = 0; j < RA_MAX_SRCS; j++)
+        if (j < np) {
+          if (sysMask >> j & 1) stSysAt(d[j] + b, lane16, v[j]);
+          else stAt(d[j] + b, lane16, v[j]);
+        }
+    }
+    done = full;
+  }
+  // what is left (ragged end, or everything when a pointer is unaligned): pair by pair, bytes
+  if (done < nbytes) {
+    for (int j = 0; j < np; j++) {
+      const int8_t* sj = (const int8_t*)uniformPtr(a.src[j]);
+      int8_t* dj = (int8_t*)uniformPtr(a.dst[j]);
+      for (size_t i = done + tid; i < nbytes; i += nthr) {
+        if (sysMask >> j & 1) stSysElem<int8_t>(dj + i, sj[i]);
+        else dj[i] = sj[i];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ local kernels
 // One rank (src/device/onerank.cu) and the exported N-source reduce-copy.
 template <typename T, int OP>
@@ -535,8 +585,18 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
+        // all n-1 pieces in one fused pass when they have the same length and need no scaling
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        size_t ne0 = 0; bool same = OP != RA_OP_PREMULSUM;
         for (int i = 0; i < n - 1; i++) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
+          size_t off, ne; R.piece(g, p, off, ne);
+          if (i == 0) ne0 = ne; else same = same && ne == ne0;
+          pa.src[i] = (const char*)(in + off); pa.dst[i] = cx.sendSlot(p, 0); pa.sysMask |= 1u << i;
+        }
+        if (same) { pairCopyWG(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
+        for (int i = 0; i < n - 1; i++) {
+          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
@@ -555,6 +615,15 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
       });
     } else {
       cx.step(peers, 1, 0, 0, [&]() {
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        size_t ne0 = 0; bool same = true;
+        for (int i = 1; i < n; i++) {
+          const int p = (r + n - i) % n;
+          size_t off, ne; R.piece(g, p, off, ne);
+          if (i == 1) ne0 = ne; else same = same && ne == ne0;
+          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = (char*)(out + off);
+        }
+        if (same) { pairCopyWG(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
           size_t off, ne; R.piece(g, p, off, ne);
@@ -581,8 +650,17 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
+        if (OP != RA_OP_PREMULSUM) {
+          RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+          for (int i = 0; i < n - 1; i++) {
+            const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
+            pa.src[i] = (const char*)(in + (size_t)p * w.count + off); pa.dst[i] = cx.sendSlot(p, 0); pa.sysMask |= 1u << i;
+          }
+          pairCopyWG(pa, ne * sizeof(T), cx.tid, cx.nthr);
+          return;
+        }
         for (int i = 0; i < n - 1; i++) {
-          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
+          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
@@ -624,12 +702,12 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
       });
     } else {
       cx.step(peers, 1, 0, 0, [&]() {
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
-          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = w.recv + (size_t)p * nbytes + off;
-          copyWG(a, nb, cx.tid, cx.nthr);
+          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = w.recv + (size_t)p * nbytes + off;
         }
+        pairCopyWG(pa, nb, cx.tid, cx.nthr);
       });
     }
   }
