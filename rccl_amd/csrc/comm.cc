@@ -17,6 +17,7 @@
 #include <map>
 
 #include "debug.h"
+#include "net.h"
 #include "topo.h"
 
 namespace {
@@ -153,6 +154,7 @@ ncclResult_t buildDevComm(ncclComm* c) {
   long ms = envLong("RCCL_AMD_SPIN_TIMEOUT_MS", 120000);
   if (ms < 1) ms = 1;
   h.timeoutTicks = (uint64_t)ms * 100000ull;
+  h.netMode = c->net ? 1u : 0u;
   h.tuneFlags = (uint32_t)envLong("RCCL_AMD_TUNE_FLAGS", 0);
   h.nRings = c->nRings;
   memcpy(h.ringRanks, c->ringRanks, sizeof h.ringRanks);
@@ -314,6 +316,16 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
     }
     c->multiProcess = true;
     if ((res = c->boot.connect(id, rank, nranks)) != ncclSuccess) break;
+    if (raNetRequested()) {
+      // Host-staged transport: few channels (one CPU thread pumps them all), windows in pinned host memory.
+      if (!getenv("RCCL_AMD_NCHANNELS") && !getenv("NCCL_MAX_NCHANNELS")) c->maxChannels = 2;
+      makeLayout(c);
+      c->clique = std::make_shared<RaClique>();
+      if ((res = raNetSetup(c)) != ncclSuccess) break;
+      if ((res = buildDevComm(c)) != ncclSuccess) break;
+      res = c->boot.barrier();
+      break;
+    }
     if ((res = allocWindow(c)) != ncclSuccess) break;
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
@@ -367,6 +379,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
   if (res != ncclSuccess) {
     RA_WARN("ncclCommInitRank failed for rank %d of %d", rank, nranks);
     c->boot.close();
+    raNetShutdown(c);
     for (int p = 0; p < nranks; p++) if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
     freeLocal(c);
     c->magic = 0;
@@ -389,6 +402,7 @@ ncclResult_t raCommDestroy(ncclComm_t c, bool abort) {
     // Peers may still be posting credits into this window: leave together.
     if (!abort) (void)c->boot.barrier();
     c->boot.close();
+    raNetShutdown(c);
     for (int p = 0; p < c->nRanks; p++)
       if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
   }

@@ -26,6 +26,8 @@ struct RaClique {
   ~RaClique();
 };
 
+struct RaNet;
+
 struct RaUserOp {
   bool used = false;
   int dtype = 0;
@@ -59,6 +61,7 @@ struct ncclComm {
   std::shared_ptr<RaClique> clique;
   RaBootstrap boot;
   bool multiProcess = false;
+  RaNet* net = nullptr;              // host-staged TCP transport state, when selected
 
   // launch ordering between user streams
   hipStream_t lastStream = nullptr;

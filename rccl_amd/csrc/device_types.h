@@ -46,12 +46,13 @@ struct RaWindowLayout {
 };
 
 // Flag word index -> byte offset.  which: 0 = tail (written by the sender `peer`),
-// 1 = head (written by the receiver `peer`).
+// 1 = head (written by the receiver `peer`), 2 + s = byte count of slot s of the FIFO from `peer`
+// (written by the sender; only the host-staged transport reads it, to know how much to ship).
 __host__ __device__ inline size_t raFlagOffset(const RaWindowLayout& l, int which, int ch, int peer, int kind) {
   return ((((size_t)which * l.nChannels + ch) * l.nRanks + peer) * RA_NKINDS + kind) * RA_FLAG_STRIDE;
 }
 __host__ __device__ inline size_t raFlagBytes(const RaWindowLayout& l) {
-  return (size_t)2 * l.nChannels * l.nRanks * RA_NKINDS * RA_FLAG_STRIDE;
+  return (size_t)(2 + l.nSlots) * l.nChannels * l.nRanks * RA_NKINDS * RA_FLAG_STRIDE;
 }
 // Slot storage of the FIFO on which `peer` sends to the window's owner.
 __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, int peer, int kind) {
@@ -68,6 +69,7 @@ struct RaDevComm {
   uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
+  uint32_t netMode;           // 1: windows are host-pinned staging areas pumped over TCP by a proxy thread
   uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = add a release fence before posting, 2 = no acquire fence
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
@@ -85,4 +87,5 @@ struct RaWork {
   size_t chunkElems;   // elements one owner handles per round (a multiple of 16 bytes)
   size_t lastChunkElems;  // same, for the final partial round
   uint64_t opArg;      // PreMulSum scalar bits / SumPostDiv divisor
+  uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
 };

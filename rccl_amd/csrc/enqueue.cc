@@ -154,6 +154,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.coll = a.coll; w.algo = p.algo; w.nChannels = p.nChannels; w.elemSize = (int)es;
   w.send = (const char*)a.send; w.recv = (char*)a.recv; w.count = a.count;
   w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg;
+  w.stepBytes = (uint32_t)(p.chunkElems * es);
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e = raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);

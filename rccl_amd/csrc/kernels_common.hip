@@ -6,7 +6,7 @@ __global__ __launch_bounds__(1024) void raGatherKernel(const RaDevComm* __restri
   __shared__ ChanShared sh;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
-  cx.init(comm, &sh, blockIdx.x % w.nChannels);
+  cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
   if (w.algo == RA_ALGO_DIRECT) directAllGather(cx, w, role);
   else ringAllGather(cx, w);
   cx.finish();

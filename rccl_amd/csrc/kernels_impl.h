@@ -435,6 +435,7 @@ struct Ctx {
   const RaDevComm* comm;
   ChanShared* sh;
   int ch, tid, nthr, rank, nRanks;
+  uint32_t stepBytes;
 
   __device__ __forceinline__ uint64_t* flag(int owner, int which, int peer, int kind) const {
     return (uint64_t*)(comm->win[owner] + raFlagOffset(comm->lay, which, ch, peer, kind));
@@ -450,7 +451,8 @@ struct Ctx {
            (sh->recvStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
   }
 
-  __device__ void init(const RaDevComm* c, ChanShared* s, int channel) {
+  __device__ void init(const RaDevComm* c, ChanShared* s, int channel, uint32_t stepBytes_) {
+    stepBytes = stepBytes_;
     comm = c; sh = s; ch = channel; tid = threadIdx.x; nthr = blockDim.x; rank = c->rank; nRanks = c->nRanks;
     const int n = nRanks * RA_NKINDS;
     if (tid < n) {
@@ -535,7 +537,11 @@ struct Ctx {
         if (sendMask >> p & 1) {            // slot published: tail in the receiver's window
           const uint64_t s = sh->sendStep[p][sk] + 1;
           sh->sendStep[p][sk] = s;
-          if (ok) stFlag(flag(p, 0, rank, sk), s);
+          if (ok) {
+            // host-staged transport: tell the proxy how many bytes this slot carries, then publish
+            if (comm->netMode) stFlag(flag(p, 2 + (int)((s - 1) % comm->lay.nSlots), rank, sk), stepBytes);
+            stFlag(flag(p, 0, rank, sk), s);
+          }
         }
       }
       if (tid == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
@@ -928,7 +934,7 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   __shared__ ChanShared sh;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
-  cx.init(comm, &sh, blockIdx.x % w.nChannels);
+  cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
   if (w.algo == RA_ALGO_DIRECT) {
     if (w.coll == RA_COLL_ALLREDUCE) directAllReduce<T, OP>(cx, w, role);
     else if (w.coll == RA_COLL_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);

@@ -1,0 +1,244 @@
+// Host-staged transport over TCP (the "net" side case).
+//
+// Reference behaviour being reproduced (src/transport/net.cc:1123-1644 send/recvProxyProgress
+// with the built-in socket plugin src/transport/net_socket.cc, selected by
+// NCCL_P2P_DISABLE=1 NCCL_SHM_DISABLE=1 NCCL_NET=Socket): the kernels are the same as for the
+// peer-to-peer transport, but their FIFOs live in pinned HOST memory; a CPU proxy thread ships
+// every published slot to the peer over a socket and relays the credits back.
+//
+// Here: each rank owns one real window in pinned host memory (what its kernels poll and read)
+// and, per peer, a local "shadow" of that peer's window with the same layout.  A kernel writes
+// into shadow(p) exactly what it would have stored into p's window over xGMI: slot data, the slot's
+// byte count, tails and heads.  The tx thread mirrors those changes to rank p over TCP; p's rx
+// thread applies them to p's real window.  Every byte therefore crosses
+// GPU -> pinned host -> TCP (loopback) -> pinned host -> GPU.
+#include "net.h"
+
+#include <arpa/inet.h>
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <poll.h>
+#include <sched.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "debug.h"
+
+namespace {
+
+enum { MSG_DATA = 1, MSG_CREDIT = 2 };
+struct MsgHeader {
+  uint32_t type, ch, kind, nbytes;
+  uint64_t step;
+};
+
+bool sendAll(int fd, const void* p, size_t n) {
+  const char* c = (const char*)p;
+  while (n) {
+    ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL);
+    if (k <= 0) { if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue; return false; }
+    c += k; n -= (size_t)k;
+  }
+  return true;
+}
+bool recvAll(int fd, void* p, size_t n) {
+  char* c = (char*)p;
+  while (n) {
+    ssize_t k = ::recv(fd, c, n, 0);
+    if (k <= 0) { if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue; return false; }
+    c += k; n -= (size_t)k;
+  }
+  return true;
+}
+
+inline uint64_t* flagAt(char* win, const RaWindowLayout& l, int which, int ch, int peer, int kind) {
+  return (uint64_t*)(win + raFlagOffset(l, which, ch, peer, kind));
+}
+
+}  // namespace
+
+struct RaNet {
+  ncclComm* c = nullptr;
+  int rank = 0, n = 0;
+  RaWindowLayout lay{};
+  char* real = nullptr;                  // host address of this rank's window
+  std::vector<char*> shadow;             // host addresses, per peer
+  std::vector<int> sock;                 // per peer
+  std::vector<uint64_t> sentTail, sentHead;   // [peer][ch][kind]
+  std::thread tx, rx;
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> bytesSent{0};
+
+  size_t ix(int p, int ch, int k) const { return ((size_t)p * lay.nChannels + ch) * RA_NKINDS + k; }
+
+  void fail(const char* what) {
+    if (stop.load()) return;
+    RA_WARN("host-staged transport: %s failed on rank %d: %s", what, rank, strerror(errno));
+    if (c->hostFlags) __atomic_store_n(&c->hostFlags[0], 1u, __ATOMIC_RELAXED);   // kernels give up
+  }
+
+  void txLoop() {
+    while (!stop.load(std::memory_order_relaxed)) {
+      bool progress = false;
+      for (int p = 0; p < n; p++) {
+        if (p == rank) continue;
+        char* sh = shadow[(size_t)p];
+        for (int ch = 0; ch < lay.nChannels; ch++)
+          for (int k = 0; k < RA_NKINDS; k++) {
+            // slots this rank's kernels published towards p
+            const uint64_t tail = __atomic_load_n(flagAt(sh, lay, 0, ch, rank, k), __ATOMIC_ACQUIRE);
+            uint64_t& st = sentTail[ix(p, ch, k)];
+            while (st < tail) {
+              const uint64_t step = st + 1;
+              const int slot = (int)((step - 1) % (uint64_t)lay.nSlots);
+              uint64_t nbytes = __atomic_load_n(flagAt(sh, lay, 2 + slot, ch, rank, k), __ATOMIC_RELAXED);
+              if (nbytes > lay.slotBytes) nbytes = lay.slotBytes;
+              MsgHeader h{MSG_DATA, (uint32_t)ch, (uint32_t)k, (uint32_t)nbytes, step};
+              const char* data = sh + raDataOffset(lay, ch, rank, k) + (size_t)slot * lay.slotBytes;
+              if (!sendAll(sock[(size_t)p], &h, sizeof h) || !sendAll(sock[(size_t)p], data, (size_t)nbytes)) { fail("send"); return; }
+              bytesSent += nbytes;
+              st = step;
+              progress = true;
+            }
+            // slots this rank's kernels consumed from p: credit back
+            const uint64_t head = __atomic_load_n(flagAt(sh, lay, 1, ch, rank, k), __ATOMIC_ACQUIRE);
+            uint64_t& shd = sentHead[ix(p, ch, k)];
+            if (shd < head) {
+              MsgHeader h{MSG_CREDIT, (uint32_t)ch, (uint32_t)k, 0, head};
+              if (!sendAll(sock[(size_t)p], &h, sizeof h)) { fail("send"); return; }
+              shd = head;
+              progress = true;
+            }
+          }
+      }
+      if (!progress) sched_yield();
+    }
+  }
+
+  void rxLoop() {
+    std::vector<struct pollfd> pf;
+    std::vector<int> who;
+    for (int p = 0; p < n; p++)
+      if (p != rank) { pf.push_back({sock[(size_t)p], POLLIN, 0}); who.push_back(p); }
+    while (!stop.load(std::memory_order_relaxed)) {
+      int r = ::poll(pf.data(), (nfds_t)pf.size(), 50);
+      if (r < 0) { if (errno == EINTR) continue; fail("poll"); return; }
+      if (r == 0) continue;
+      for (size_t i = 0; i < pf.size(); i++) {
+        if (!(pf[i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+        const int p = who[i];
+        MsgHeader h;
+        if (!recvAll(pf[i].fd, &h, sizeof h)) { if (!stop.load()) fail("recv"); return; }
+        if ((int)h.ch >= lay.nChannels || h.kind >= RA_NKINDS || h.nbytes > lay.slotBytes) { errno = EPROTO; fail("message check"); return; }
+        if (h.type == MSG_DATA) {
+          const int slot = (int)((h.step - 1) % (uint64_t)lay.nSlots);
+          char* dst = real + raDataOffset(lay, (int)h.ch, p, (int)h.kind) + (size_t)slot * lay.slotBytes;
+          if (h.nbytes && !recvAll(pf[i].fd, dst, h.nbytes)) { if (!stop.load()) fail("recv"); return; }
+          __atomic_store_n(flagAt(real, lay, 0, (int)h.ch, p, (int)h.kind), h.step, __ATOMIC_RELEASE);
+        } else if (h.type == MSG_CREDIT) {
+          __atomic_store_n(flagAt(real, lay, 1, (int)h.ch, p, (int)h.kind), h.step, __ATOMIC_RELEASE);
+        } else {
+          errno = EPROTO; fail("message type"); return;
+        }
+      }
+    }
+  }
+};
+
+bool raNetRequested() {
+  // NCCL_P2P_DISABLE=1 turns the peer-to-peer transport off (src/graph/paths.cc:287-291); this
+  // library has no shared-memory transport, so the next choice is the socket transport, exactly
+  // what NCCL_SHM_DISABLE=1 NCCL_NET=Socket makes of the reference.
+  const char* e = getenv("NCCL_P2P_DISABLE");
+  return e && atoi(e) != 0;
+}
+
+ncclResult_t raNetSetup(ncclComm* c) {
+  RaNet* N = new RaNet;
+  c->net = N;
+  N->c = c; N->rank = c->rank; N->n = c->nRanks; N->lay = c->lay;
+  const size_t bytes = c->lay.totalBytes;
+  N->shadow.assign((size_t)N->n, nullptr);
+  N->sock.assign((size_t)N->n, -1);
+  N->sentTail.assign((size_t)N->n * c->lay.nChannels * RA_NKINDS, 0);
+  N->sentHead.assign((size_t)N->n * c->lay.nChannels * RA_NKINDS, 0);
+  // pinned, GPU-mapped host memory (the reference: ncclCudaHostCalloc, src/transport/net.cc:798-800)
+  for (int p = 0; p < N->n; p++) {
+    void* h = nullptr;
+    RA_HIP(hipHostMalloc(&h, bytes, hipHostMallocMapped));
+    memset(h, 0, c->lay.dataOffset);
+    void* d = nullptr;
+    RA_HIP(hipHostGetDevicePointer(&d, h, 0));
+    if (p == c->rank) N->real = (char*)h; else N->shadow[(size_t)p] = (char*)h;
+    c->peerWin[p] = (char*)d;
+  }
+  RA_INFO("rank %d: host-staged transport, %d windows of %zu MiB in pinned host memory", c->rank, N->n, bytes >> 20);
+
+  // full mesh of loopback sockets: ports are exchanged over the bootstrap, lower rank connects
+  int lfd = ::socket(AF_INET, SOCK_STREAM, 0);
+  if (lfd < 0) return ncclSystemError;
+  struct sockaddr_in sa; memset(&sa, 0, sizeof sa);
+  sa.sin_family = AF_INET; sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK); sa.sin_port = 0;
+  socklen_t sl = sizeof sa;
+  if (::bind(lfd, (struct sockaddr*)&sa, sizeof sa) || ::listen(lfd, 64) || ::getsockname(lfd, (struct sockaddr*)&sa, &sl)) {
+    RA_WARN("host-staged transport: cannot listen: %s", strerror(errno));
+    ::close(lfd);
+    return ncclSystemError;
+  }
+  std::vector<uint32_t> ports((size_t)N->n);
+  uint32_t mine = ntohs(sa.sin_port);
+  ncclResult_t res = c->boot.allGather(&mine, ports.data(), sizeof mine);
+  if (res != ncclSuccess) { ::close(lfd); return res; }
+  const int one = 1, big = 8 << 20;
+  for (int p = N->rank + 1; p < N->n; p++) {          // connect to the higher ranks
+    int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    struct sockaddr_in pa; memset(&pa, 0, sizeof pa);
+    pa.sin_family = AF_INET; pa.sin_addr.s_addr = htonl(INADDR_LOOPBACK); pa.sin_port = htons((uint16_t)ports[(size_t)p]);
+    if (fd < 0 || ::connect(fd, (struct sockaddr*)&pa, sizeof pa)) { RA_WARN("host-staged transport: connect to rank %d: %s", p, strerror(errno)); ::close(lfd); return ncclSystemError; }
+    int32_t me = N->rank;
+    if (!sendAll(fd, &me, sizeof me)) { ::close(lfd); return ncclSystemError; }
+    N->sock[(size_t)p] = fd;
+  }
+  for (int k = 0; k < N->rank; k++) {                  // accept the lower ranks
+    int fd = ::accept(lfd, nullptr, nullptr);
+    int32_t who = -1;
+    if (fd < 0 || !recvAll(fd, &who, sizeof who) || who < 0 || who >= N->rank || N->sock[(size_t)who] >= 0) {
+      RA_WARN("host-staged transport: accept failed: %s", strerror(errno));
+      ::close(lfd);
+      return ncclSystemError;
+    }
+    N->sock[(size_t)who] = fd;
+  }
+  ::close(lfd);
+  for (int p = 0; p < N->n; p++)
+    if (N->sock[(size_t)p] >= 0) {
+      setsockopt(N->sock[(size_t)p], IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+      setsockopt(N->sock[(size_t)p], SOL_SOCKET, SO_SNDBUF, &big, sizeof big);
+      setsockopt(N->sock[(size_t)p], SOL_SOCKET, SO_RCVBUF, &big, sizeof big);
+    }
+  N->tx = std::thread([N]() { N->txLoop(); });
+  N->rx = std::thread([N]() { N->rxLoop(); });
+  return ncclSuccess;
+}
+
+void raNetShutdown(ncclComm* c) {
+  RaNet* N = c->net;
+  if (!N) return;
+  N->stop.store(true);
+  for (int fd : N->sock) if (fd >= 0) ::shutdown(fd, SHUT_RDWR);
+  if (N->tx.joinable()) N->tx.join();
+  if (N->rx.joinable()) N->rx.join();
+  for (int fd : N->sock) if (fd >= 0) ::close(fd);
+  if (N->real) (void)hipHostFree(N->real);
+  for (char* s : N->shadow) if (s) (void)hipHostFree(s);
+  RA_INFO("rank %d: host-staged transport shipped %llu payload bytes", c->rank, (unsigned long long)N->bytesSent.load());
+  delete N;
+  c->net = nullptr;
+}

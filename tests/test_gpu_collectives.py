@@ -149,3 +149,30 @@ def test_back_to_back_and_reinit(bed):
     outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, count, ins, count * 4)
     for o in outs:
         assert np.array_equal(o.view(np.int32), want)
+
+
+def test_host_staged_tcp_transport(bed):
+    """NCCL_P2P_DISABLE=1: every hop goes GPU -> pinned host -> loopback TCP -> pinned host -> GPU
+    (the reference's socket transport, src/transport/net.cc + net_socket.cc).  Same kernels, same results."""
+    if bed.nranks > 4:
+        pytest.skip("kept to 2 and 4 ranks: 8 proxy-thread pairs on a 16-core box only add time")
+    try:
+        bed.init_comms({"NCCL_P2P_DISABLE": "1", "RCCL_AMD_NCHANNELS": "2", "NCCL_ALGO": None})
+        n = bed.nranks
+        for dt, op, count in ((orc.F32, orc.SUM, 393216), (orc.I32, orc.SUM, 1250), (orc.BF16, orc.SUM, 100003),
+                              (orc.F32, orc.AVG, 70001)):
+            _check_allreduce(bed, dt, op, count)
+        count = 54235
+        ins = [orc.fill_pattern(orc.I32, count * n, r) for r in range(n)]
+        outs = bed.run(COLL_REDUCESCATTER, orc.I32, orc.PROD, count, ins, count * 4)
+        for r in range(n):
+            assert np.array_equal(outs[r].view(np.int32), orc.reduce_scatter_expected(orc.I32, orc.PROD, ins, r))
+        ins = [orc.fill_pattern(orc.U8, 1039203, r) for r in range(n)]
+        outs = bed.run(COLL_ALLGATHER, orc.U8, orc.SUM, 1039203, ins, 1039203 * n)
+        for r in range(n):
+            assert np.array_equal(outs[r], orc.all_gather_expected(ins))
+        bed.init_comms({"NCCL_P2P_DISABLE": "1", "RCCL_AMD_NCHANNELS": "2", "NCCL_ALGO": "Ring"})
+        _check_allreduce(bed, orc.F32, orc.SUM, 393216)
+    finally:
+        bed.destroy_comms()
+        bed.init_comms({"NCCL_P2P_DISABLE": None, "RCCL_AMD_NCHANNELS": bed.base_env["RCCL_AMD_NCHANNELS"], "NCCL_ALGO": None})

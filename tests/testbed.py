@@ -123,6 +123,7 @@ class TestBed:
         base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "10000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60",
                     "RCCL_AMD_NCHANNELS": str(max(2, min(16, 64 // per_gpu)))}
         base_env.update(env or {})
+        self.base_env = dict(base_env)
         self.conns, self.procs = [], []
         for r in range(nranks):
             parent, child = ctx.Pipe()
