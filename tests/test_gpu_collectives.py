@@ -151,6 +151,29 @@ def test_back_to_back_and_reinit(bed):
         assert np.array_equal(o.view(np.int32), want)
 
 
+def test_hip_graph_capture_and_replay(bed):
+    """Collectives captured into a hipGraph and replayed (the reference's graph-mode cases, e.g.
+    AllReduceTests.cpp:29-46): step counters live in device memory, so a replay continues the FIFOs."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n = bed.nranks
+    count = 12888
+    for dt, op in ((orc.F16, orc.MIN), (orc.F64, orc.MIN), (orc.I32, orc.MAX)):
+        ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+        outs = bed.run(COLL_ALLREDUCE, dt, op, count, ins, count * _es(dt), graph=True)
+        want = orc.host_fold(dt, op, ins)
+        for o in outs:
+            assert ex.check(dt, o, want, exact=True) is None
+    ins = [orc.fill_pattern(orc.BF16, 586, r) for r in range(n)]
+    outs = bed.run(COLL_ALLGATHER, orc.BF16, orc.SUM, 586, ins, 586 * n * 2, graph=True)
+    for o in outs:
+        assert ex.check(orc.BF16, o, orc.all_gather_expected(ins), exact=True) is None
+    count = 104857
+    ins = [orc.fill_pattern(orc.F64, count * n, r) for r in range(n)]
+    outs = bed.run(COLL_REDUCESCATTER, orc.F64, orc.MAX, count, ins, count * 8, graph=True)
+    for r in range(n):
+        assert ex.check(orc.F64, outs[r], orc.reduce_scatter_expected(orc.F64, orc.MAX, ins, r), exact=True) is None
+
+
 def test_host_staged_tcp_transport(bed):
     """NCCL_P2P_DISABLE=1: every hop goes GPU -> pinned host -> loopback TCP -> pinned host -> GPU
     (the reference's socket transport, src/transport/net.cc + net_socket.cc).  Same kernels, same results."""

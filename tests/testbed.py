@@ -71,8 +71,29 @@ def _child(rank, nranks, device, conn, env):
                     user_op = comm.create_premul_sum(a["premul"], a["dtype"])
                     op = user_op
                 torch.cuda.synchronize()
+
+                def issue():
+                    if a["coll"] == COLL_ALLREDUCE:
+                        comm.all_reduce(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
+                    elif a["coll"] == COLL_REDUCESCATTER:
+                        comm.reduce_scatter(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
+                    else:
+                        comm.all_gather(send_ptr, recv_ptr, a["count"], a["dtype"], stream)
+
+                if a.get("graph"):
+                    # hipGraph mode of the reference's tests (TestBed.cpp:614-765): capture once, replay twice
+                    if a["in_place"]:
+                        raise ValueError("graph replays of an in-place reduction would re-reduce its output")
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        issue()
+                    g.replay()
+                    stream.synchronize()
+                    out_view().fill_(0x3C)
+                    torch.cuda.synchronize()
+                    g.replay()
                 with torch.cuda.stream(stream):
-                    for _ in range(a.get("iters", 1)):
+                    for _ in range(0 if a.get("graph") else a.get("iters", 1)):
                         if a["in_place"] and a.get("iters", 1) > 1:
                             raise ValueError("in-place with iters>1 would re-reduce its own output")
                         if a["coll"] == COLL_ALLREDUCE:
@@ -157,12 +178,13 @@ class TestBed:
         self.inited = True
         return info
 
-    def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1):
+    def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
-                     out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters)
+                     out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
+                     graph=graph)
                 for r in range(self.nranks)]
         res = self._all("coll", args)
         for r, (err, _) in enumerate(res):
