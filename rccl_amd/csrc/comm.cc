@@ -60,6 +60,9 @@ void readTunables(ncclComm* c) {
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
+  // NCCL_PROTO (src/graph/tuning.cc:476-485): "Simple" keeps small all-reduces off the low-latency path
+  const char* pr = getenv("NCCL_PROTO");
+  c->allowLL = !(pr && *pr && !strcasestr(pr, "LL"));
   c->algoEnv = -1;
   const char* a = getenv("NCCL_ALGO");    // src/graph/tuning.cc:476-485
   if (a && *a) {
@@ -86,7 +89,9 @@ void makeLayout(ncclComm* c) {
   if (slotBytes < 4096) slotBytes = 4096;
   l.slotBytes = (uint32_t)alignUp((size_t)slotBytes, 4096);
   l.dataOffset = alignUp(raFlagBytes(l), 4096);
-  l.totalBytes = raDataOffset(l, l.nChannels, 0, 0);   // one past the last FIFO
+  l.llOffset = alignUp(raDataOffset(l, l.nChannels, 0, 0), 4096);   // one past the last FIFO
+  l.llBytes = (size_t)RA_LL_MAX_BYTES * 2;                          // 16-byte line per 8 bytes of payload
+  l.totalBytes = raLLOffset(l, 2, 0);
 }
 
 ncclResult_t allocWindow(ncclComm* c) {
@@ -108,6 +113,7 @@ ncclResult_t allocWindow(ncclComm* c) {
   (void)hipGetLastError();
   c->window = (char*)p;
   RA_HIP(hipMemset(p, 0, c->lay.dataOffset));   // all flag words start at zero
+  RA_HIP(hipMemset((char*)p + c->lay.llOffset, 0, c->lay.totalBytes - c->lay.llOffset));   // no line carries a live epoch
   RA_HIP(hipDeviceSynchronize());
   RA_INFO("rank %d: window %p, %zu MiB (%d channels x %d ranks x %d kinds x %d slots x %u KiB)", c->rank, p,
           c->lay.totalBytes >> 20, c->lay.nChannels, c->nRanks, RA_NKINDS, c->lay.nSlots, c->lay.slotBytes >> 10);
@@ -134,6 +140,8 @@ ncclResult_t buildDevComm(ncclComm* c) {
   const size_t nSteps = (size_t)c->lay.nChannels * c->nRanks * RA_NKINDS;
   RA_HIP(hipMalloc((void**)&c->steps, 2 * nSteps * sizeof(uint64_t)));
   RA_HIP(hipMemset(c->steps, 0, 2 * nSteps * sizeof(uint64_t)));
+  RA_HIP(hipMalloc((void**)&c->llEpoch, RA_LL_GRID * sizeof(uint32_t)));
+  RA_HIP(hipMemset(c->llEpoch, 0, RA_LL_GRID * sizeof(uint32_t)));
   RA_HIP(hipHostMalloc((void**)&c->hostFlags, 64, hipHostMallocMapped));
   memset(c->hostFlags, 0, 64);
   RA_HIP(hipHostGetDevicePointer((void**)&c->hostFlagsDev, c->hostFlags, 0));
@@ -148,6 +156,7 @@ ncclResult_t buildDevComm(ncclComm* c) {
   for (int p = 0; p < c->nRanks; p++) h.win[p] = c->peerWin[p];
   h.sendStep = c->steps;
   h.recvStep = c->steps + nSteps;
+  h.llEpoch = c->llEpoch;
   h.abortFlag = c->hostFlagsDev;
   h.errorFlag = c->hostFlagsDev + 1;
   // wall_clock64() ticks at 100 MHz on gfx950
@@ -184,6 +193,8 @@ ncclResult_t enablePeer(int myDev, int peerDev) {
 void freeLocal(ncclComm* c) {
   if (c->devComm) (void)hipFree(c->devComm);
   if (c->steps) (void)hipFree(c->steps);
+  if (c->llEpoch) (void)hipFree(c->llEpoch);
+  c->llEpoch = nullptr;
   if (c->hostFlags) (void)hipHostFree(c->hostFlags);
   if (c->orderEvent) (void)hipEventDestroy(c->orderEvent);
   c->devComm = nullptr; c->steps = nullptr; c->hostFlags = nullptr; c->orderEvent = nullptr;

@@ -44,6 +44,7 @@ struct ncclComm {
   int maxChannels = 16;
   int blockThreads = 512;
   int algoEnv = -1;          // NCCL_ALGO: -1 unset
+  bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol
   size_t minChunkBytes = 32 << 10;
 
   // device resources
@@ -53,6 +54,7 @@ struct ncclComm {
   bool peerIsIpc[RA_MAX_RANKS] = {};
   RaDevComm* devComm = nullptr;
   uint64_t* steps = nullptr;         // sendStep + recvStep
+  uint32_t* llEpoch = nullptr;       // per low-latency workgroup launch counters (device)
   uint32_t* hostFlags = nullptr;     // pinned, mapped: [0] abort request, [1] device error
   uint32_t* hostFlagsDev = nullptr;
   int nRings = 0;
@@ -97,7 +99,7 @@ struct RaCollArgs {
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
 ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, RaPlan* plan);
+                       size_t minChunkBytes, int blockThreads, bool allowLL, RaPlan* plan);
 ncclResult_t raEnqueue(const RaCollArgs& a);
 ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();

@@ -42,6 +42,8 @@ struct RaWindowLayout {
   int nSlots;         // FIFO depth (reference NCCL_STEPS = 8, src/include/device.h:32)
   uint32_t slotBytes; // bytes per slot (reference step size 512 KiB, src/init.cc:839)
   size_t dataOffset;  // start of the slot storage inside the window
+  size_t llOffset;    // start of the low-latency line buffers (2 buffers x nRanks senders)
+  size_t llBytes;     // bytes of one sender's line buffer (16 B per 8 B of payload)
   size_t totalBytes;
 };
 
@@ -59,6 +61,16 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
   return l.dataOffset + ((((size_t)ch * l.nRanks + peer) * RA_NKINDS + kind) * l.nSlots) * (size_t)l.slotBytes;
 }
 
+// Low-latency protocol (reference: src/device/prims_ll.h:137-260): 16-byte lines
+// {data lo, flag, data hi, flag}; the flag is the launch epoch, so data and "ready" arrive in one
+// store and the receiver needs no separate flag round trip.
+#define RA_LL_MAX_BYTES (256u << 10)   // largest payload the one-shot low-latency all-reduce takes
+#define RA_LL_GRID 8                   // workgroups of every low-latency launch (fixed: each keeps its own epoch)
+#define RA_LL_THREADS 1024
+__host__ __device__ inline size_t raLLOffset(const RaWindowLayout& l, int buf, int sender) {
+  return l.llOffset + ((size_t)buf * l.nRanks + sender) * l.llBytes;
+}
+
 struct RaDevComm {
   int rank;
   int nRanks;
@@ -66,6 +78,7 @@ struct RaDevComm {
   char* win[RA_MAX_RANKS];    // win[rank] is local; the others are peer mappings
   uint64_t* sendStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has published
   uint64_t* recvStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has consumed
+  uint32_t* llEpoch;          // [RA_LL_GRID] launches each low-latency workgroup has run
   uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks

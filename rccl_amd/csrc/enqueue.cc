@@ -157,7 +157,8 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.stepBytes = (uint32_t)(p.chunkElems * es);
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
-  hipError_t e = raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);
+  hipError_t e = p.proto == 1 ? raLaunchLL(c->devComm, w, a.dtype, devOp, a.stream)
+                              : raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);
   if (e != hipSuccess) { RA_WARN("collective kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
   return ncclSuccess;
 }
@@ -189,7 +190,7 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
 // (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
 // and NCCL_ALGO selects the ring or chain schedules.
 ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, RaPlan* p) {
+                       size_t minChunkBytes, int blockThreads, bool allowLL, RaPlan* p) {
   const size_t es = raTypeSize(dtype);
   if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
   int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
@@ -226,12 +227,20 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
     p->lastChunkElems = last;
   }
   p->grid = gridFor(coll, algo, p->nChannels);
+  // Small all-reduces on the all-pairs schedule take the one-shot low-latency protocol
+  // (the reference switches to LL below 256-512 KiB, src/graph/tuning.cc:632-671).
+  if (allowLL && coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && n > 1 && count * es <= RA_LL_MAX_BYTES) {
+    p->proto = 1;
+    p->nChannels = RA_LL_GRID;
+    p->grid = RA_LL_GRID;
+    p->block = RA_LL_THREADS;
+  }
   return ncclSuccess;
 }
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
   return raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
-                   c->blockThreads, p);
+                   c->blockThreads, c->allowLL && !c->net, p);
 }
 
 int raGroupDepth() { return tGroupDepth; }

@@ -14,7 +14,8 @@ __global__ __launch_bounds__(1024) void raGatherKernel(const RaDevComm* __restri
 
 #define RA_DECL(N)                                                                                             \
   hipError_t raLaunchCollDt##N(const RaDevComm*, const RaWork&, int op, int grid, int block, hipStream_t s);  \
-  hipError_t raLaunchLocalDt##N(const RcArgs&, size_t nelem, int op, int grid, hipStream_t s);
+  hipError_t raLaunchLocalDt##N(const RcArgs&, size_t nelem, int op, int grid, hipStream_t s);         \
+  hipError_t raLaunchLLDt##N(const RaDevComm*, const RaWork&, int op, hipStream_t s);
 RA_DECL(0) RA_DECL(1) RA_DECL(2) RA_DECL(3) RA_DECL(4) RA_DECL(5) RA_DECL(6) RA_DECL(7) RA_DECL(8) RA_DECL(9)
 #undef RA_DECL
 
@@ -25,6 +26,15 @@ hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int o
   }
   switch (dtype) {
 #define RA_CASE(N) case N: return raLaunchCollDt##N(comm, w, op, grid, block, s);
+    RA_CASE(0) RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8) RA_CASE(9)
+#undef RA_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t raLaunchLL(const RaDevComm* comm, const RaWork& w, int dtype, int op, hipStream_t s) {
+  switch (dtype) {
+#define RA_CASE(N) case N: return raLaunchLLDt##N(comm, w, op, s);
     RA_CASE(0) RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8) RA_CASE(9)
 #undef RA_CASE
     default: return hipErrorInvalidValue;

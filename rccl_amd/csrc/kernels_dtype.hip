@@ -39,6 +39,11 @@ static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int b
   return hipGetLastError();
 }
 template <int OP>
+static hipError_t llOp(const RaDevComm* comm, const RaWork& w, hipStream_t s) {
+  hipLaunchKernelGGL((raLLAllReduceKernel<elem_t, OP>), dim3(RA_LL_GRID), dim3(RA_LL_THREADS), 0, s, comm, w);
+  return hipGetLastError();
+}
+template <int OP>
 static hipError_t localOp(const RcArgs& a, size_t nelem, int grid, hipStream_t s) {
   hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(RA_LOCAL_THREADS), 0, s, a, nelem);
   return hipGetLastError();
@@ -54,6 +59,20 @@ hipError_t RA_CAT(raLaunchCollDt, RA_DTYPE)(const RaDevComm* comm, const RaWork&
     case RA_OP_PREMULSUM: return collOp<RA_OP_PREMULSUM>(comm, w, grid, block, s);
 #if RA_IS_INT
     case RA_OP_SUMPOSTDIV: return collOp<RA_OP_SUMPOSTDIV>(comm, w, grid, block, s);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t RA_CAT(raLaunchLLDt, RA_DTYPE)(const RaDevComm* comm, const RaWork& w, int op, hipStream_t s) {
+  switch (op) {
+    case RA_OP_SUM: return llOp<RA_OP_SUM>(comm, w, s);
+    case RA_OP_PROD: return llOp<RA_OP_PROD>(comm, w, s);
+    case RA_OP_MAX: return llOp<RA_OP_MAX>(comm, w, s);
+    case RA_OP_MIN: return llOp<RA_OP_MIN>(comm, w, s);
+    case RA_OP_PREMULSUM: return llOp<RA_OP_PREMULSUM>(comm, w, s);
+#if RA_IS_INT
+    case RA_OP_SUMPOSTDIV: return llOp<RA_OP_SUMPOSTDIV>(comm, w, s);
 #endif
     default: return hipErrorInvalidValue;
   }

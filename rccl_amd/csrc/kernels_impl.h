@@ -927,6 +927,115 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
   }
 }
 
+// ------------------------------------------------------------------ low-latency one-shot all-reduce
+// For small payloads: every rank stores its whole input, as 16-byte {lo, epoch, hi, epoch} lines,
+// into every peer's line buffer, then folds the n contributions in rank order as they arrive.
+// One network hop, no barriers, no flag words.  Two line buffers alternate by epoch parity; a rank
+// cannot get two launches ahead of a peer because finishing a launch needs every peer's lines.
+// Role of the reference's LL all-reduce for small sizes (src/device/prims_ll.h, selected below
+// 256-512 KiB by src/graph/tuning.cc:632-671), on the all-pairs schedule.
+template <typename T>
+__device__ __forceinline__ uint64_t llLoadUnit(const T* in, size_t u, size_t count) {
+  constexpr int EPU = 8 / sizeof(T);
+  const size_t e0 = u * EPU;
+  if (e0 + EPU <= count && ((uintptr_t)in & 7) == 0) return ((const uint64_t*)in)[u];
+  union { uint64_t w; T e[EPU]; } x; x.w = 0;
+  for (int i = 0; i < EPU; i++) if (e0 + i < count) x.e[i] = in[e0 + i];
+  return x.w;
+}
+template <typename T>
+__device__ __forceinline__ void llStoreUnit(T* out, size_t u, size_t count, uint64_t w) {
+  constexpr int EPU = 8 / sizeof(T);
+  const size_t e0 = u * EPU;
+  if (e0 + EPU <= count && ((uintptr_t)out & 7) == 0) { ((uint64_t*)out)[u] = w; return; }
+  union { uint64_t w; T e[EPU]; } x; x.w = w;
+  for (int i = 0; i < EPU; i++) if (e0 + i < count) out[e0 + i] = x.e[i];
+}
+template <typename T, int OP>
+__device__ __forceinline__ uint64_t llRed(uint64_t a, uint64_t b) {
+  constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+  constexpr int EPU = 8 / sizeof(T);
+  union { uint64_t w; T e[EPU]; } x, y; x.w = a; y.w = b;
+#pragma unroll
+  for (int i = 0; i < EPU; i++) x.e[i] = Elem<T, R>::red(x.e[i], y.e[i]);
+  return x.w;
+}
+template <typename T, bool PRE>
+__device__ __forceinline__ uint64_t llScale(uint64_t a, uint64_t arg) {
+  constexpr int EPU = 8 / sizeof(T);
+  union { uint64_t w; T e[EPU]; } x; x.w = a;
+#pragma unroll
+  for (int i = 0; i < EPU; i++) x.e[i] = PRE ? Scale<T>::pre(x.e[i], arg) : Scale<T>::post(x.e[i], arg);
+  return x.w;
+}
+__device__ __forceinline__ u32x4 llLoadLine(const char* p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  const int n = comm->nRanks, r = comm->rank;
+  uint32_t epoch = comm->llEpoch[blockIdx.x] + 1;
+  if (epoch == 0) epoch = 1;
+  const int buf = (int)(epoch & 1u);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t nUnits = (w.count * sizeof(T) + 7) / 8;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+  // 1. my contribution to everyone
+  for (size_t u = gtid; u < nUnits; u += gsize) {
+    uint64_t v = llLoadUnit<T>(in, u, w.count);
+    if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
+    u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
+    for (int i = 1; i < n; i++) {
+      const int p = (r + i) % n;
+      stSys((u32x4*)(comm->win[p] + raLLOffset(comm->lay, buf, r)) + u, line);
+    }
+  }
+  // 2. fold what arrives, in rank order
+  bool dead = false;
+  for (size_t u = gtid; u < nUnits; u += gsize) {
+    uint64_t acc = 0;
+    for (int q = 0; q < n; q++) {
+      uint64_t x;
+      if (q == r) {
+        x = llLoadUnit<T>(in, u, w.count);
+        if (OP == RA_OP_PREMULSUM) x = llScale<T, true>(x, w.opArg);
+      } else {
+        const char* lp = comm->win[r] + raLLOffset(comm->lay, buf, q) + u * 16;
+        u32x4 line = llLoadLine(lp);
+        if (!dead && (line.y != epoch || line.w != epoch)) {
+          const uint64_t t0 = wall_clock64();
+          uint32_t spins = 0;
+          do {
+            __builtin_amdgcn_s_sleep(1);
+            line = llLoadLine(lp);
+            if ((++spins & 0xff) == 0) {
+              const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+              if (asked || wall_clock64() - t0 > comm->timeoutTicks) {
+                uint32_t expect = RA_ERR_NONE;
+                __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
+                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
+                break;
+              }
+            }
+          } while (line.y != epoch || line.w != epoch);
+        }
+        x = (uint64_t)line.x | ((uint64_t)line.z << 32);
+      }
+      acc = q == 0 ? x : llRed<T, OP>(acc, x);
+    }
+    if (OP == RA_OP_SUMPOSTDIV) acc = llScale<T, false>(acc, w.opArg);
+    if (!dead) llStoreUnit<T>(out, u, w.count, acc);
+  }
+  // 3. this workgroup has run one more launch (every thread is past its reads of the old value)
+  __syncthreads();
+  if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
+}
+
 // ------------------------------------------------------------------ the collective kernel
 // grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.
 template <typename T, int OP>

@@ -6,6 +6,9 @@
 // grid = roles * w.nChannels workgroups of `block` threads on stream s.
 hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int op, int grid, int block, hipStream_t s);
 
+// One-shot low-latency all-reduce (payload <= RA_LL_MAX_BYTES): RA_LL_GRID x RA_LL_THREADS threads.
+hipError_t raLaunchLL(const RaDevComm* comm, const RaWork& w, int dtype, int op, hipStream_t s);
+
 // Local kernels run RA_LOCAL_THREADS threads per workgroup; one workgroup moves RA_LOCAL_TILE_BYTES of
 // output per pass (1024 threads x 128 B in flight each: the shape that measured fastest for a 1 GiB copy,
 // 6.28 TB/s, with one tile per workgroup).

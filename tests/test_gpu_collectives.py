@@ -151,6 +151,25 @@ def test_back_to_back_and_reinit(bed):
         assert np.array_equal(o.view(np.int32), want)
 
 
+def test_low_latency_protocol(bed):
+    """Small all-reduces take the one-shot low-latency protocol unless NCCL_PROTO=Simple; both give the
+    rank-order fold (StandaloneTests.cpp:177-187 runs its known-answer case under LL and Simple)."""
+    n = bed.nranks
+    x = np.arange(1250, dtype=np.int32)
+    for proto, want_proto in ((None, 1), ("Simple", 0), ("LL", 1)):
+        bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": proto})
+        assert bed.plan(COLL_ALLREDUCE, 1250, orc.I32)["proto"] == want_proto
+        assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] == 0          # large: always the FIFO protocol
+        outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 1250, [x] * n, 1250 * 4, iters=7)
+        for o in outs:
+            assert np.array_equal(o.view(np.int32), n * x)
+        for dt, op, count in ((orc.F32, orc.SUM, 384), (orc.F16, orc.MIN, 12888), (orc.I8, orc.PROD, 383), (orc.U8, orc.SUM, 2501),
+                              (orc.BF16, orc.AVG, 65536 + 3), (orc.I64, orc.AVG, 1023), (orc.F64, orc.SUM, 32768), (orc.F32, orc.SUM, 65536)):
+            _check_allreduce(bed, dt, op, count)
+        _check_allreduce(bed, orc.I32, orc.PROD, 384, in_place=True)
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
+
+
 def test_hip_graph_capture_and_replay(bed):
     """Collectives captured into a hipGraph and replayed (the reference's graph-mode cases, e.g.
     AllReduceTests.cpp:29-46): step counters live in device memory, so a replay continues the FIFOs."""
