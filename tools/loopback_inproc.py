@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Several ranks of one communicator inside ONE process on ONE GPU (ncclCommInitAll with a repeated
+device, ncclGroupStart/End, one stream per rank).  No xGMI is involved: all traffic is HBM, so this shows
+what the collective kernels and the FIFO protocol cost by themselves, and it can run under rocprofv3
+(one process, no launcher).  Not a scaling number.
+
+    python3 tools/loopback_inproc.py --ranks 2 --bytes 1073741824 --iters 10
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ranks", type=int, default=2)
+    ap.add_argument("--bytes", type=int, default=1 << 30)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    os.environ["RCCL_AMD_MULTI_RANK_GPU"] = "1"
+    os.environ.setdefault("RCCL_AMD_SPIN_TIMEOUT_MS", "20000")
+    os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // a.ranks)))
+    import torch
+    import rccl_amd as ra
+    n, count = a.ranks, a.bytes // 4
+    comms = ra.Communicator.init_all(n, [0] * n)
+    streams = [torch.cuda.Stream() for _ in range(n)]
+    ins = [torch.rand(count, device="cuda") for _ in range(n)]
+    outs = [torch.zeros(count, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+
+    def step():
+        ra.group_start()
+        for r in range(n):
+            comms[r].all_reduce(ins[r], outs[r], count, ra.ncclFloat32, ra.ncclSum, streams[r])
+        ra.group_end()
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+    for r in range(n):
+        e0[r].record(streams[r])
+    for _ in range(a.iters):
+        step()
+    for r in range(n):
+        e1[r].record(streams[r])
+    torch.cuda.synchronize()
+    ms = max(e0[r].elapsed_time(e1[r]) for r in range(n)) / a.iters
+    want = ins[0].clone()
+    for r in range(1, n):
+        want += ins[r]
+    ok = all(torch.equal(o, want) for o in outs) and all(c.async_error() == 0 for c in comms)
+    hbm = (2 + 4 * (n - 1) / n) * a.bytes * n           # bytes all ranks move through HBM per all-reduce
+    print(json.dumps({"ranks_on_one_gpu": n, "bytes": a.bytes, "ms_per_allreduce": round(ms, 4), "exact": ok,
+                      "plan": comms[0].plan_info(0, count, ra.ncclFloat32),
+                      "hbm_bytes_all_ranks": hbm, "hbm_GBps": round(hbm / ms / 1e6, 1)}))
+    for c in comms:
+        c.destroy()
+
+
+if __name__ == "__main__":
+    main()
