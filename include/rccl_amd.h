@@ -71,8 +71,8 @@ typedef enum {
   ncclMaxRedOp = 0x7fffffff >> (32 - 8 * sizeof(ncclRedOp_dummy_t))
 } ncclRedOp_t;
 
-/* nccl.h.in:364-377.  The two fp8 types are accepted by ncclAllGather (a byte
- * copy) and rejected with ncclInvalidArgument by the reducing collectives. */
+/* nccl.h.in:364-377.  The two fp8 types use the reference's encoding (src/include/rccl_float8.h:
+ * exponent bias 2^(we-1), 0x80 is NaN, no infinities), not the OCP one. */
 typedef enum {
   ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3,
   ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7,

@@ -26,14 +26,14 @@
 
 /* ncclDataType_t values, src/nccl.h.in:364-377 */
 enum { DT_I8 = 0, DT_U8 = 1, DT_I32 = 2, DT_U32 = 3, DT_I64 = 4, DT_U64 = 5,
-       DT_F16 = 6, DT_F32 = 7, DT_F64 = 8, DT_BF16 = 9 };
+       DT_F16 = 6, DT_F32 = 7, DT_F64 = 8, DT_BF16 = 9, DT_F8E4M3 = 10, DT_F8E5M2 = 11 };
 /* ncclRedOp_t values, src/nccl.h.in:353-358 */
 enum { OP_SUM = 0, OP_PROD = 1, OP_MAX = 2, OP_MIN = 3, OP_AVG = 4 };
 
 size_t orc_type_size(int dt) {
   /* test/common/PtrUnion.cpp:11-31 */
   switch (dt) {
-    case DT_I8: case DT_U8: return 1;
+    case DT_I8: case DT_U8: case DT_F8E4M3: case DT_F8E5M2: return 1;
     case DT_F16: case DT_BF16: return 2;
     case DT_I32: case DT_U32: case DT_F32: return 4;
     case DT_I64: case DT_U64: case DT_F64: return 8;
@@ -97,6 +97,53 @@ float orc_f16_to_f32(uint16_t h) {
   return bits_f32(sign | ((exp - 15 + 127) << 23) | (mant << 13));
 }
 
+/* ---- 8-bit floats ------------------------------------------------------------
+ * The reference's rccl_float8 (E4M3, wm=3) and rccl_bfloat8 (E5M2, wm=2) in the encoding where
+ * 0x80 is NaN and there is no negative zero or infinity: exponent bias 2^(we-1)
+ * (src/include/rccl_float8.h:137,301-302).  Conversion from float rounds to nearest even;
+ * NaN/Inf -> 0x80; a magnitude beyond the largest finite value saturates to it, because the
+ * reference builds with clipping on (rccl_float8.h:48,221-229,412-415).
+ * Restated arithmetically; pinned code by code against tests/golden/ref_fp8_*.csv, which
+ * oracle/gen_golden_fp8.cc produces from the reference header itself.                          */
+static float f8_decode(uint8_t x, int wm) {
+  const int we = 7 - wm, bias = 1 << (we - 1);
+  if (x == 0) return 0.0f;
+  if (x == 0x80) return bits_f32(0x7f800001u);
+  const int sign = x >> 7, e = (x & 0x7f) >> wm, m = x & ((1 << wm) - 1);
+  const float mag = e ? ldexpf((float)((1 << wm) | m), e - bias - wm) : ldexpf((float)m, 1 - bias - wm);
+  return sign ? -mag : mag;
+}
+static uint8_t f8_encode(float f, int wm) {
+  const int we = 7 - wm, bias = 1 << (we - 1), maxExp = (1 << we) - 1;
+  const uint32_t u = f32_bits(f);
+  if ((u & 0x7f800000u) == 0x7f800000u) return 0x80;
+  const uint32_t sign = u >> 31;
+  const float a = fabsf(f);
+  if (a == 0.0f) return 0;
+  int e2;
+  (void)frexpf(a, &e2);
+  int E = e2 - 1;                                   /* a = 1.xxx * 2^E */
+  int expField, mant;
+  if (E < 1 - bias) {                               /* below the smallest normal: fixed quantum */
+    const float r = nearbyintf(ldexpf(a, -(1 - bias - wm)));
+    const int q = (int)r;
+    if (q == 0) return 0;
+    if (q >= (1 << wm)) { expField = 1; mant = q - (1 << wm); }
+    else { expField = 0; mant = q; }
+  } else {
+    int q = (int)nearbyintf(ldexpf(a, -(E - wm)));  /* in [2^wm, 2^(wm+1)] */
+    if (q == (1 << (wm + 1))) { E++; q = 1 << wm; }
+    expField = E + bias;
+    mant = q - (1 << wm);
+  }
+  if (expField > maxExp) return (uint8_t)((sign << 7) | 0x7f);     /* clip to the largest finite value */
+  return (uint8_t)((sign << 7) | ((uint32_t)expField << wm) | (uint32_t)mant);
+}
+float orc_f8e4m3_to_f32(uint8_t x) { return f8_decode(x, 3); }
+float orc_f8e5m2_to_f32(uint8_t x) { return f8_decode(x, 2); }
+uint8_t orc_f32_to_f8e4m3(float f) { return f8_encode(f, 3); }
+uint8_t orc_f32_to_f8e5m2(float f) { return f8_encode(f, 2); }
+
 /* ---- input pattern --------------------------------------------------------
  * test/common/PtrUnion.cpp:135-168 (FillPattern) + 170-191 (Set):
  * valueI = (rank+i)%256 ; valueF = 1/(valueI+1) in double, narrowed to T.   */
@@ -115,6 +162,8 @@ int orc_fill_pattern(int dt, size_t n, int rank, void* out) {
       case DT_F32: ((float*)out)[i]    = (float)vf; break;
       case DT_F64: ((double*)out)[i]   = vf; break;
       case DT_BF16:((uint16_t*)out)[i] = orc_f32_to_bf16((float)vf); break;
+      case DT_F8E4M3: ((uint8_t*)out)[i] = orc_f32_to_f8e4m3((float)vf); break;
+      case DT_F8E5M2: ((uint8_t*)out)[i] = orc_f32_to_f8e5m2((float)vf); break;
       default: return -1;
     }
   }
@@ -151,6 +200,10 @@ static inline uint16_t op_f16(int op, uint16_t a, uint16_t b) {
   return orc_f32_to_f16(op_f32(op, orc_f16_to_f32(a), orc_f16_to_f32(b))); }
 static inline uint16_t op_bf16(int op, uint16_t a, uint16_t b) {
   return orc_f32_to_bf16(op_f32(op, orc_bf16_to_f32(a), orc_bf16_to_f32(b))); }
+/* fp8: every op goes through float and back (reduce_kernel.h:267-272; PtrUnion.cpp:270,274) */
+typedef uint8_t f8a; typedef uint8_t f8b;
+static inline uint8_t op_f8a(int op, uint8_t a, uint8_t b) { return f8_encode(op_f32(op, f8_decode(a, 3), f8_decode(b, 3)), 3); }
+static inline uint8_t op_f8b(int op, uint8_t a, uint8_t b) { return f8_encode(op_f32(op, f8_decode(a, 2), f8_decode(b, 2)), 2); }
 
 /* acc[i] = acc[i] (op) in[i] — one hop of any fold.  op is Sum/Prod/Max/Min. */
 int orc_reduce_into(int dt, int op, size_t n, void* acc, const void* in) {
@@ -166,6 +219,8 @@ int orc_reduce_into(int dt, int op, size_t n, void* acc, const void* in) {
     case DT_F32: LOOP(float, op_f32);
     case DT_F64: LOOP(double, op_f64);
     case DT_BF16:LOOP(uint16_t, op_bf16);
+    case DT_F8E4M3: LOOP(uint8_t, op_f8a);
+    case DT_F8E5M2: LOOP(uint8_t, op_f8b);
     default: return -1;
   }
 #undef LOOP
@@ -187,6 +242,8 @@ static int reduce_local_first(int dt, int op, size_t n, void* acc, const void* i
     case DT_F32: LOOP(float, op_f32);
     case DT_F64: LOOP(double, op_f64);
     case DT_BF16:LOOP(uint16_t, op_bf16);
+    case DT_F8E4M3: LOOP(uint8_t, op_f8a);
+    case DT_F8E5M2: LOOP(uint8_t, op_f8b);
     default: return -1;
   }
 #undef LOOP
@@ -208,6 +265,8 @@ int orc_divide_by_int(int dt, size_t n, void* buf, int d) {
       case DT_F32: ((float*)buf)[i] /= d; break;
       case DT_F64: ((double*)buf)[i] /= d; break;
       case DT_BF16:((uint16_t*)buf)[i] = orc_f32_to_bf16(orc_bf16_to_f32(((uint16_t*)buf)[i]) / d); break;
+      case DT_F8E4M3: ((uint8_t*)buf)[i] = f8_encode(f8_decode(((uint8_t*)buf)[i], 3) / d, 3); break;
+      case DT_F8E5M2: ((uint8_t*)buf)[i] = f8_encode(f8_decode(((uint8_t*)buf)[i], 2) / d, 2); break;
       default: return -1;
     }
   }
@@ -228,11 +287,15 @@ int orc_premul(int dt, size_t n, void* buf, int nranks) {
                    for (size_t i = 0; i < n; i++) p[i] = orc_f32_to_f16(orc_f16_to_f32(p[i]) * s); } break;
     case DT_BF16:{ float s = orc_bf16_to_f32(orc_f32_to_bf16((float)(1.0 / nranks))); uint16_t* p = buf;
                    for (size_t i = 0; i < n; i++) p[i] = orc_f32_to_bf16(orc_bf16_to_f32(p[i]) * s); } break;
+    case DT_F8E4M3: { float s = f8_decode(f8_encode((float)(1.0 / nranks), 3), 3); uint8_t* p = buf;
+                      for (size_t i = 0; i < n; i++) p[i] = f8_encode(f8_decode(p[i], 3) * s, 3); } break;
+    case DT_F8E5M2: { float s = f8_decode(f8_encode((float)(1.0 / nranks), 2), 2); uint8_t* p = buf;
+                      for (size_t i = 0; i < n; i++) p[i] = f8_encode(f8_decode(p[i], 2) * s, 2); } break;
     default: return -1;
   }
   return 0;
 }
-static int is_float_dt(int dt) { return dt == DT_F16 || dt == DT_F32 || dt == DT_F64 || dt == DT_BF16; }
+static int is_float_dt(int dt) { return dt == DT_F16 || dt == DT_F32 || dt == DT_F64 || dt >= DT_BF16; }
 
 /* ---- the reference's HOST expected value ---------------------------------
  * test/common/PrepDataFuncs.cpp:95-146: result = in[0]; for r=1..n-1
@@ -330,6 +393,8 @@ long orc_first_mismatch(int dt, size_t n, const void* got, const void* want) {
       case DT_I64: case DT_U64: ok = ((const u64*)got)[i] == ((const u64*)want)[i]; break;
       case DT_F16:  ok = fabs(orc_f16_to_f32(((const uint16_t*)got)[i]) - orc_f16_to_f32(((const uint16_t*)want)[i])) < 9e-2; break;
       case DT_BF16: ok = fabs(orc_bf16_to_f32(((const uint16_t*)got)[i]) - orc_bf16_to_f32(((const uint16_t*)want)[i])) < 9e-2; break;
+      case DT_F8E4M3: ok = fabs(f8_decode(((const u8*)got)[i], 3) - f8_decode(((const u8*)want)[i], 3)) < 9e-2; break;
+      case DT_F8E5M2: ok = fabs(f8_decode(((const u8*)got)[i], 2) - f8_decode(((const u8*)want)[i], 2)) < 9e-2; break;
       case DT_F32:  ok = fabs(((const float*)got)[i] - ((const float*)want)[i]) < 1e-5; break;
       case DT_F64:  ok = fabs(((const double*)got)[i] - ((const double*)want)[i]) < 1e-12; break;
       default: return 0;

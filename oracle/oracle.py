@@ -14,14 +14,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 # ncclDataType_t (reference src/nccl.h.in:364-377)
-I8, U8, I32, U32, I64, U64, F16, F32, F64, BF16 = range(10)
+I8, U8, I32, U32, I64, U64, F16, F32, F64, BF16, F8E4M3, F8E5M2 = range(12)
 # ncclRedOp_t (reference src/nccl.h.in:353-358)
 SUM, PROD, MAX, MIN, AVG = range(5)
 
 NP_OF = {I8: np.int8, U8: np.uint8, I32: np.int32, U32: np.uint32, I64: np.int64,
-         U64: np.uint64, F16: np.float16, F32: np.float32, F64: np.float64, BF16: np.uint16}
+         U64: np.uint64, F16: np.float16, F32: np.float32, F64: np.float64, BF16: np.uint16,
+         F8E4M3: np.uint8, F8E5M2: np.uint8}
 DT_NAMES = {I8: "int8", U8: "uint8", I32: "int32", U32: "uint32", I64: "int64", U64: "uint64",
-            F16: "fp16", F32: "fp32", F64: "fp64", BF16: "bf16"}
+            F16: "fp16", F32: "fp32", F64: "fp64", BF16: "bf16", F8E4M3: "fp8e4m3", F8E5M2: "fp8e5m2"}
 OP_NAMES = {SUM: "sum", PROD: "prod", MAX: "max", MIN: "min", AVG: "avg"}
 
 
@@ -63,6 +64,12 @@ def lib():
         for name in ("orc_bf16_to_f32", "orc_f16_to_f32"):
             getattr(L, name).restype = ctypes.c_float
             getattr(L, name).argtypes = [ctypes.c_uint16]
+        for name in ("orc_f32_to_f8e4m3", "orc_f32_to_f8e5m2"):
+            getattr(L, name).restype = ctypes.c_uint8
+            getattr(L, name).argtypes = [ctypes.c_float]
+        for name in ("orc_f8e4m3_to_f32", "orc_f8e5m2_to_f32"):
+            getattr(L, name).restype = ctypes.c_float
+            getattr(L, name).argtypes = [ctypes.c_uint8]
         L.orc_cvt_f32_to_bf16.argtypes = [sz, vp, vp]
         L.orc_cvt_f32_to_f16.argtypes = [sz, vp, vp]
         L.orc_cvt_f16_to_f32.argtypes = [sz, vp, vp]

@@ -115,7 +115,7 @@ RA_API ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, nccl
   RA_CHECK(raCommCheck(comm, "ncclRedOpCreatePreMulSum"));
   if (!op || !scalar) return ncclInvalidArgument;
   const size_t es = raTypeSize(datatype);
-  if (es == 0 || datatype == ncclFp8E4M3 || datatype == ncclFp8E5M2) { RA_WARN("ncclRedOpCreatePreMulSum: unsupported datatype %d", datatype); return ncclInvalidArgument; }
+  if (es == 0) { RA_WARN("ncclRedOpCreatePreMulSum: unsupported datatype %d", datatype); return ncclInvalidArgument; }
   for (int i = 0; i < RA_MAX_USER_OPS; i++) {
     if (comm->userOps[i].used) continue;
     RaUserOp& u = comm->userOps[i];
@@ -168,7 +168,7 @@ RA_API ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_
 RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, size_t count, ncclDataType_t datatype,
                                       ncclRedOp_t op, hipStream_t stream) {
   if (!dst || !srcs || nsrc < 1 || nsrc > RA_MAX_SRCS) { RA_WARN("rcclAmdReduceCopy: 1..%d sources", RA_MAX_SRCS); return ncclInvalidArgument; }
-  if (datatype < 0 || datatype > ncclBfloat16 || op < 0 || op > ncclMin) { RA_WARN("rcclAmdReduceCopy: unsupported type/op"); return ncclInvalidArgument; }
+  if (datatype < 0 || datatype >= ncclNumTypes || op < 0 || op > ncclMin) { RA_WARN("rcclAmdReduceCopy: unsupported type/op"); return ncclInvalidArgument; }
   if (count == 0) return ncclSuccess;
   const size_t bytes = count * raTypeSize(datatype);
   const int grid = raLocalGrid(bytes, nsrc);

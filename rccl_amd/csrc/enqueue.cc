@@ -6,6 +6,7 @@
 // group bracket (src/group.cc:96-102,384-448).  One kernel launch per collective per
 // rank; the work descriptor travels as a kernel argument instead of through a work FIFO.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <string.h>
 
 #include <thread>
@@ -64,6 +65,30 @@ uint16_t f32ToBf16Bits(float f) {  // as hip_bfloat16
   return (uint16_t)(u >> 16);
 }
 
+// float -> the reference's 8-bit floats (bias 2^(we-1), 0x80 = NaN, round to nearest even, clipped;
+// src/include/rccl_float8.h), used for the average's 1/nranks scalar.
+uint8_t f32ToF8Bits(float f, int wm) {
+  const int we = 7 - wm, bias = 1 << (we - 1), maxExp = (1 << we) - 1;
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return 0x80;
+  const uint32_t sign = (u >> 31) << 7;
+  const float a = fabsf(f);
+  if (a == 0.0f) return 0;
+  int e2; (void)frexpf(a, &e2);
+  int E = e2 - 1, expField, mant;
+  if (E < 1 - bias) {
+    const int q = (int)nearbyintf(ldexpf(a, -(1 - bias - wm)));
+    if (q == 0) return 0;
+    if (q >= (1 << wm)) { expField = 1; mant = q - (1 << wm); } else { expField = 0; mant = q; }
+  } else {
+    int q = (int)nearbyintf(ldexpf(a, -(E - wm)));
+    if (q == (1 << (wm + 1))) { E++; q = 1 << wm; }
+    expField = E + bias; mant = q - (1 << wm);
+  }
+  if (expField > maxExp) return (uint8_t)(sign | 0x7f);
+  return (uint8_t)(sign | ((uint32_t)expField << wm) | (uint32_t)mant);
+}
+
 // ncclRedOp_t + datatype -> device op and its scalar (src/enqueue.cc:1962-2057).
 ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, uint64_t* arg, const void** argPtr) {
   *arg = 0; *argPtr = nullptr;
@@ -79,6 +104,8 @@ ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, ui
           *devOp = RA_OP_SUMPOSTDIV; *arg = (uint64_t)n; return ncclSuccess;
         case ncclFloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToF16Bits(float(1.0 / n)); return ncclSuccess;
         case ncclBfloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToBf16Bits(float(1.0 / n)); return ncclSuccess;
+        case ncclFp8E4M3: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 3); return ncclSuccess;
+        case ncclFp8E5M2: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 2); return ncclSuccess;
         case ncclFloat32: { float s = float(1.0 / n); uint32_t u; memcpy(&u, &s, 4); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
         case ncclFloat64: { double s = 1.0 / n; uint64_t u; memcpy(&u, &s, 8); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
         default: return ncclInvalidArgument;
@@ -168,10 +195,6 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
   RA_CHECK(raCommCheck(a.comm, name));
   if (a.dtype < 0 || a.dtype >= ncclNumTypes) { RA_WARN("%s: invalid type %d", name, a.dtype); return ncclInvalidArgument; }
   if (a.coll != RA_COLL_ALLGATHER) {
-    if (a.dtype == ncclFp8E4M3 || a.dtype == ncclFp8E5M2) {
-      RA_WARN("%s: fp8 reductions are not provided by this library", name);
-      return ncclInvalidArgument;
-    }
     if (a.op < 0 || (a.op >= ncclNumOps && (a.op - ncclNumOps >= RA_MAX_USER_OPS || !a.comm->userOps[a.op - ncclNumOps].used))) {
       RA_WARN("%s: invalid reduction operation %d", name, a.op);
       return ncclInvalidArgument;

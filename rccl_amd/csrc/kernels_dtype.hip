@@ -1,10 +1,10 @@
-// One translation unit per element type: compiled ten times with -DRA_DTYPE=0..9 (the
+// One translation unit per element type: compiled twelve times with -DRA_DTYPE=0..11 (the
 // ncclDataType_t value) so that the builds run in parallel.  Holds the collective kernel
 // and the local reduce-copy kernel for every reduction op of that type.
 #include "kernels_impl.h"
 
 #ifndef RA_DTYPE
-#error "compile with -DRA_DTYPE=<ncclDataType_t value 0..9>"
+#error "compile with -DRA_DTYPE=<ncclDataType_t value 0..11>"
 #endif
 
 #if RA_DTYPE == 0
@@ -27,6 +27,10 @@ typedef float elem_t;
 typedef double elem_t;
 #elif RA_DTYPE == 9
 typedef bf16_t elem_t;
+#elif RA_DTYPE == 10
+typedef f8e4m3_t elem_t;
+#elif RA_DTYPE == 11
+typedef f8e5m2_t elem_t;
 #endif
 #define RA_IS_INT (RA_DTYPE <= 5)
 

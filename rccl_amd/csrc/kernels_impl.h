@@ -33,6 +33,46 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   bf16_t r; r.v = (uint16_t)(u >> 16); return r;
 }
 
+// 8-bit floats in the reference's encoding (rccl_float8 = E4M3, rccl_bfloat8 = E5M2; 0x80 is NaN, no
+// negative zero, no infinity, bias 2^(we-1); src/include/rccl_float8.h:61-329).  Conversion from float
+// rounds to nearest even and clips to the largest finite value (rccl_float8.h:48).
+template <int WM> struct f8_t { uint8_t v; };
+typedef f8_t<3> f8e4m3_t;
+typedef f8_t<2> f8e5m2_t;
+template <int WM> __device__ __forceinline__ float f8ToF(f8_t<WM> a) {
+  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1);
+  const uint32_t x = a.v;
+  if (x == 0) return 0.0f;
+  if (x == 0x80) return __uint_as_float(0x7f800001u);
+  const uint32_t sign = (x >> 7) << 31, e = (x & 0x7f) >> WM, m = x & ((1u << WM) - 1u);
+  if (e == 0) return __uint_as_float(__float_as_uint((float)m * __uint_as_float((uint32_t)(127 + 1 - BIAS - WM) << 23)) | sign);
+  return __uint_as_float(sign | ((e + 127 - BIAS) << 23) | (m << (23 - WM)));
+}
+template <int WM> __device__ __forceinline__ f8_t<WM> fToF8(float f) {
+  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1), MAXEXP = (1 << WE) - 1;
+  f8_t<WM> r;
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7f800000u) == 0x7f800000u) { r.v = 0x80; return r; }
+  const uint32_t sign = (u >> 31) << 7;
+  const float a = __uint_as_float(u & 0x7fffffffu);
+  int E = (int)((u >> 23) & 0xffu) - 127;
+  if (E == -127) { r.v = 0; return r; }                  // zero or a float subnormal: far below half a quantum
+  int expField, mant;
+  if (E < 1 - BIAS) {                                    // below the smallest normal: fixed quantum 2^(1-BIAS-WM)
+    const int q = (int)rintf(a * __uint_as_float((uint32_t)(127 + BIAS - 1 + WM) << 23));
+    if (q == 0) { r.v = 0; return r; }
+    if (q >= (1 << WM)) { expField = 1; mant = q - (1 << WM); } else { expField = 0; mant = q; }
+  } else {
+    int q = (int)rintf(a * __uint_as_float((uint32_t)(127 - (E - WM)) << 23));   // in [2^WM, 2^(WM+1)]
+    if (q == (1 << (WM + 1))) { E++; q = 1 << WM; }
+    expField = E + BIAS;
+    mant = q - (1 << WM);
+  }
+  if (expField > MAXEXP) { r.v = (uint8_t)(sign | 0x7f); return r; }
+  r.v = (uint8_t)(sign | ((uint32_t)expField << WM) | (uint32_t)mant);
+  return r;
+}
+
 template <typename T> struct IsInt { static constexpr bool value = true; };
 template <> struct IsInt<float> { static constexpr bool value = false; };
 template <> struct IsInt<double> { static constexpr bool value = false; };
@@ -78,6 +118,12 @@ template <int OP> struct Elem<bf16_t, OP> {
   }
 };
 
+template <int WM, int OP> struct Elem<f8_t<WM>, OP> {   // through float and back (reduce_kernel.h:267-272)
+  static __device__ __forceinline__ f8_t<WM> red(f8_t<WM> a, f8_t<WM> b) {
+    return fToF8<WM>(Elem<float, OP>::red(f8ToF<WM>(a), f8ToF<WM>(b)));
+  }
+};
+
 // Pre-multiply (FuncPreMulSum, reduce_kernel.h:364-531) and post-divide
 // (FuncSumPostDiv, reduce_kernel.h:546-573).  `arg` carries the scalar's bits.
 template <typename T> __device__ __forceinline__ T argAs(uint64_t arg) {
@@ -90,6 +136,10 @@ template <typename T> struct Scale {
 template <> struct Scale<bf16_t> {
   static __device__ __forceinline__ bf16_t pre(bf16_t a, uint64_t arg) { return f2bf(bf2f(a) * bf2f(argAs<bf16_t>(arg))); }
   static __device__ __forceinline__ bf16_t post(bf16_t a, uint64_t) { return a; }
+};
+template <int WM> struct Scale<f8_t<WM>> {
+  static __device__ __forceinline__ f8_t<WM> pre(f8_t<WM> a, uint64_t arg) { return fToF8<WM>(f8ToF<WM>(a) * f8ToF<WM>(argAs<f8_t<WM>>(arg))); }
+  static __device__ __forceinline__ f8_t<WM> post(f8_t<WM> a, uint64_t) { return a; }
 };
 template <> struct Scale<f16_t> {
   static __device__ __forceinline__ f16_t pre(f16_t a, uint64_t arg) { return a * argAs<f16_t>(arg); }
@@ -109,25 +159,66 @@ template <typename T> union Pack {
   u32x4 v;
   T e[16 / sizeof(T)];
 };
-template <typename T, int OP> __device__ __forceinline__ u32x4 packRed(u32x4 a, u32x4 b) {
-  constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
-  Pack<T> x, y; x.v = a; y.v = b;
+template <typename T, int OP> struct PackOps {
+  static __device__ __forceinline__ u32x4 red(u32x4 a, u32x4 b) {
+    constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+    Pack<T> x, y; x.v = a; y.v = b;
 #pragma unroll
-  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Elem<T, R>::red(x.e[i], y.e[i]);
-  return x.v;
-}
-template <typename T> __device__ __forceinline__ u32x4 packPre(u32x4 a, uint64_t arg) {
-  Pack<T> x; x.v = a;
+    for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Elem<T, R>::red(x.e[i], y.e[i]);
+    return x.v;
+  }
+  static __device__ __forceinline__ u32x4 pre(u32x4 a, uint64_t arg) {
+    Pack<T> x; x.v = a;
 #pragma unroll
-  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::pre(x.e[i], arg);
-  return x.v;
-}
-template <typename T> __device__ __forceinline__ u32x4 packPost(u32x4 a, uint64_t arg) {
-  Pack<T> x; x.v = a;
+    for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::pre(x.e[i], arg);
+    return x.v;
+  }
+  static __device__ __forceinline__ u32x4 post(u32x4 a, uint64_t arg) {
+    Pack<T> x; x.v = a;
 #pragma unroll
-  for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::post(x.e[i], arg);
-  return x.v;
+    for (int i = 0; i < (int)(16 / sizeof(T)); i++) x.e[i] = Scale<T>::post(x.e[i], arg);
+    return x.v;
+  }
+};
+// The 8-bit floats convert in software (about 40 instructions each way), so their pack ops stay out
+// of line, four elements per call: the copy loops around them keep their shape and the code stays small.
+template <int WM, int R> __device__ __noinline__ uint32_t f8Red4(uint32_t a, uint32_t b) {
+  uint32_t r = 0;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    f8_t<WM> x, y; x.v = (uint8_t)(a >> (8 * i)); y.v = (uint8_t)(b >> (8 * i));
+    r |= (uint32_t)Elem<f8_t<WM>, R>::red(x, y).v << (8 * i);
+  }
+  return r;
 }
+template <int WM> __device__ __noinline__ uint32_t f8Pre4(uint32_t a, uint32_t arg) {
+  uint32_t r = 0;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) {
+    f8_t<WM> x; x.v = (uint8_t)(a >> (8 * i));
+    r |= (uint32_t)Scale<f8_t<WM>>::pre(x, arg).v << (8 * i);
+  }
+  return r;
+}
+template <int WM, int OP> struct PackOps<f8_t<WM>, OP> {
+  static __device__ __forceinline__ u32x4 red(u32x4 a, u32x4 b) {
+    constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+    u32x4 r;
+    r.x = f8Red4<WM, R>(a.x, b.x); r.y = f8Red4<WM, R>(a.y, b.y);
+    r.z = f8Red4<WM, R>(a.z, b.z); r.w = f8Red4<WM, R>(a.w, b.w);
+    return r;
+  }
+  static __device__ __forceinline__ u32x4 pre(u32x4 a, uint64_t arg) {
+    u32x4 r;
+    r.x = f8Pre4<WM>(a.x, (uint32_t)arg); r.y = f8Pre4<WM>(a.y, (uint32_t)arg);
+    r.z = f8Pre4<WM>(a.z, (uint32_t)arg); r.w = f8Pre4<WM>(a.w, (uint32_t)arg);
+    return r;
+  }
+  static __device__ __forceinline__ u32x4 post(u32x4 a, uint64_t) { return a; }
+};
+template <typename T, int OP> __device__ __forceinline__ u32x4 packRed(u32x4 a, u32x4 b) { return PackOps<T, OP>::red(a, b); }
+template <typename T> __device__ __forceinline__ u32x4 packPre(u32x4 a, uint64_t arg) { return PackOps<T, RA_OP_SUM>::pre(a, arg); }
+template <typename T> __device__ __forceinline__ u32x4 packPost(u32x4 a, uint64_t arg) { return PackOps<T, RA_OP_SUM>::post(a, arg); }
 
 // Global-address-space accesses (never flat): nontemporal 16-byte loads and stores.
 typedef __attribute__((address_space(1))) const u32x4 gc_u32x4;
