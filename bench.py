@@ -182,7 +182,8 @@ def main():
             traffic = None
 
     line = {
-        "metric": "AllReduce bus-bandwidth GB/s, 1 GiB fp32 sum" if args.coll == "allreduce" else f"{args.coll} bus-bandwidth GB/s",
+        "metric": ("AllReduce bus-bandwidth GB/s, 1 GiB fp32 sum" if (args.coll == "allreduce" and args.dtype == "fp32" and S == 1 << 30)
+                   else f"{args.coll} bus-bandwidth GB/s, {S} B per rank, {args.dtype}"),
         "value": round(busbw, 3), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(per_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
