@@ -156,7 +156,7 @@ ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, siz
  * link is used the same number of times when such a set exists. */
 ncclResult_t rcclAmdTopoRings(int ngpus, const int* adj, int maxRings, int* rings, int* nrings);
 
-/* Parses a topology XML in the reference's format (tools/topo_expl/models/*.xml, written by
+/* Parses a topology XML in the reference's format (the .xml files under tools/topo_expl/models, written by
  * src/graph/xml.cc) and fills the ngpus x ngpus direct-xGMI adjacency matrix.  `adj` must hold
  * maxGpus*maxGpus ints; *ngpus receives the GPU count. */
 ncclResult_t rcclAmdTopoParseXml(const char* xmlText, int maxGpus, int* adj, int* ngpus);

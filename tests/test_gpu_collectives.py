@@ -224,3 +224,28 @@ def test_host_staged_tcp_transport(bed):
     finally:
         bed.destroy_comms()
         bed.init_comms({"NCCL_P2P_DISABLE": None, "RCCL_AMD_NCHANNELS": bed.base_env["RCCL_AMD_NCHANNELS"], "NCCL_ALGO": None})
+
+
+def test_missing_peer_is_detected_not_hung():
+    """Failure detection (reference: abort flag polled by every device spin, prims_simple.h:82-92, surfaced by
+    ncclCommGetAsyncError, init.cc:2842-2849).  A rank that never joins a collective must not hang the others:
+    their device-side waits expire, the error is reported asynchronously, later calls fail, ncclCommAbort cleans up."""
+    tb = TestBed(2, devices=_devices(), env={"RCCL_AMD_SPIN_TIMEOUT_MS": "1500"})
+    try:
+        tb.init_comms()
+        count = 1 << 20
+        ins = [orc.fill_pattern(orc.F32, count, r) for r in range(2)]
+        errs = tb.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4, skip_ranks=(1,), expect_errors=True)
+        assert errs[0] == 6 and errs[1] == 0                     # ncclRemoteError on the rank that waited
+        assert tb.command(0, "try_coll") == 6                    # the communicator stays failed
+        tb.command(0, "abort")
+        tb.command(1, "destroy")
+        tb.inited = False
+        # fresh communicators on the same processes work again
+        tb.init_comms()
+        outs = tb.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4)
+        want = orc.host_fold(orc.F32, orc.SUM, ins)
+        for o in outs:
+            assert np.array_equal(o.view(np.float32), want)
+    finally:
+        tb.close()

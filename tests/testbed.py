@@ -41,6 +41,21 @@ def _child(rank, nranks, device, conn, env):
                         os.environ[k] = v
                 comm = ra.Communicator.init_rank(nranks, uid, rank)
                 conn.send(("ok", (comm.count(), comm.user_rank(), comm.cu_device())))
+            elif cmd == "coll" and args.get("skip"):
+                conn.send(("ok", (0, b"")))            # this rank sits the collective out (failure tests)
+            elif cmd == "abort":
+                if comm is not None:
+                    comm.abort()
+                    comm = None
+                conn.send(("ok", None))
+            elif cmd == "try_coll":
+                # a collective on a communicator that already failed must return its error code
+                t = torch.zeros(64, dtype=torch.float32, device="cuda")
+                try:
+                    comm.all_reduce(t, t, 64, ra.ncclFloat32, ra.ncclSum, stream)
+                    conn.send(("ok", 0))
+                except ra.NcclError as e:
+                    conn.send(("ok", e.code))
             elif cmd == "coll":
                 # args: dict(coll, dtype, op, count, input(np bytes), out_bytes, in_place, premul(bytes|None), iters)
                 a = args
@@ -178,18 +193,25 @@ class TestBed:
         self.inited = True
         return info
 
-    def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False):
+    def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False,
+            skip_ranks=(), expect_errors=False):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                      out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
-                     graph=graph)
+                     graph=graph, skip=r in skip_ranks)
                 for r in range(self.nranks)]
         res = self._all("coll", args)
+        if expect_errors:
+            return [err for err, _ in res]
         for r, (err, _) in enumerate(res):
             assert err == 0, f"rank {r}: asynchronous error {err}"
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
+
+    def command(self, rank, cmd, args=None):
+        self.conns[rank].send((cmd, args))
+        return self._recv(rank)
 
     def plan(self, coll, count, dtype):
         self.conns[0].send(("plan", (coll, count, dtype)))
