@@ -123,15 +123,18 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
 ncclResult_t ncclGroupStart(void);                                           /* nccl.h.in:808 */
 ncclResult_t ncclGroupEnd(void);                                             /* nccl.h.in:818 */
 
-/* ---- declared by the reference, outside this library's path ----------------- */
-/* These exist so that a program using them still links; each returns
- * ncclInvalidUsage and records a message for ncclGetLastError. */
+/* ---- one-to-all / all-to-one, one hop over the all-pairs links ------------------------------ */
+/* recvbuff may be NULL off the root of ncclReduce, sendbuff off the root of ncclBroadcast. */
 ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
                         ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream);  /* nccl.h.in:458 */
 ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
                            int root, ncclComm_t comm, hipStream_t stream);               /* nccl.h.in:499 */
 ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
                        hipStream_t stream);                                              /* nccl.h.in:478 */
+
+/* ---- declared by the reference, outside this library's path ----------------- */
+/* These exist so that a program using them still links; each returns
+ * ncclInvalidUsage and records a message for ncclGetLastError. */
 ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer,
                       ncclComm_t comm, hipStream_t stream);                              /* nccl.h.in:587 */
 ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,

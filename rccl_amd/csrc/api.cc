@@ -158,9 +158,21 @@ static ncclResult_t outOfScope(const char* name) {
   RA_WARN("%s is outside this library's path (all-reduce, reduce-scatter, all-gather)", name);
   return ncclInvalidUsage;
 }
-RA_API ncclResult_t ncclReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclReduce"); }
-RA_API ncclResult_t ncclBroadcast(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclBroadcast"); }
-RA_API ncclResult_t ncclBcast(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclBcast"); }
+RA_API ncclResult_t ncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                               int root, ncclComm_t comm, hipStream_t stream) {
+  // src/collectives.cc ncclReduce_impl
+  RaCollArgs a{RA_COLL_REDUCE, sendbuff, recvbuff, count, (int)datatype, (int)op, comm, stream, root};
+  return raEnqueue(a);
+}
+RA_API ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root,
+                                  ncclComm_t comm, hipStream_t stream) {
+  // src/collectives.cc ncclBroadcast_impl
+  RaCollArgs a{RA_COLL_BROADCAST, sendbuff, recvbuff, count, (int)datatype, (int)ncclSum, comm, stream, root};
+  return raEnqueue(a);
+}
+RA_API ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) {
+  return ncclBroadcast(buff, buff, count, datatype, root, comm, stream);   // the deprecated in-place form
+}
 RA_API ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclSend"); }
 RA_API ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclRecv"); }
 RA_API ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) { return outOfScope("ncclCommSplit"); }
@@ -181,7 +193,7 @@ RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int ns
 RA_API ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll, size_t count, ncclDataType_t datatype, int* algo, int* proto,
                                     int* nChannels, size_t* chunkElems) {
   RA_CHECK(raCommCheck(comm, "rcclAmdPlanInfo"));
-  if (coll < 0 || coll > RA_COLL_ALLGATHER) return ncclInvalidArgument;
+  if (coll < 0 || coll >= RA_NUM_COLLS) return ncclInvalidArgument;
   RaPlan p;
   RA_CHECK(raPlan(comm, coll, count, datatype, &p));
   if (algo) *algo = p.algo;

@@ -96,6 +96,7 @@ struct RaCollArgs {
   int op;                    // ncclRedOp_t value (may be a user op handle)
   ncclComm* comm;
   hipStream_t stream;
+  int root = 0;              // broadcast / reduce
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
 ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,

@@ -26,7 +26,8 @@
 #define RA_MAX_SRCS 8   // sources / destinations of one reduce-copy
 
 // collectives
-enum { RA_COLL_ALLREDUCE = 0, RA_COLL_REDUCESCATTER = 1, RA_COLL_ALLGATHER = 2 };
+enum { RA_COLL_ALLREDUCE = 0, RA_COLL_REDUCESCATTER = 1, RA_COLL_ALLGATHER = 2, RA_COLL_BROADCAST = 3, RA_COLL_REDUCE = 4,
+       RA_NUM_COLLS = 5 };
 // algorithms
 enum { RA_ALGO_DIRECT = 0, RA_ALGO_RING = 1, RA_ALGO_TREE = 2 };
 // device reduction ops (reference ncclDevRedOp_t, src/include/device.h; built by
@@ -83,7 +84,7 @@ struct RaDevComm {
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
   uint32_t netMode;           // 1: windows are host-pinned staging areas pumped over TCP by a proxy thread
-  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = add a release fence before posting, 2 = no acquire fence
+  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = no release fence, 2 = no acquire fence (breaks results), 4 = system-scope release
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
@@ -101,4 +102,5 @@ struct RaWork {
   size_t lastChunkElems;  // same, for the final partial round
   uint64_t opArg;      // PreMulSum scalar bits / SumPostDiv divisor
   uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
+  int root;            // broadcast / reduce
 };

@@ -144,7 +144,8 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   ncclComm* c = a.comm;
   const size_t es = raTypeSize(a.dtype);
   int devOp = RA_OP_SUM; uint64_t arg = 0; const void* argPtr = nullptr;
-  if (a.coll != RA_COLL_ALLGATHER) RA_CHECK(translateOp(c, a.op, a.dtype, &devOp, &arg, &argPtr));
+  const bool reduces = a.coll != RA_COLL_ALLGATHER && a.coll != RA_COLL_BROADCAST;
+  if (reduces) RA_CHECK(translateOp(c, a.op, a.dtype, &devOp, &arg, &argPtr));
   DeviceGuard guard;
   guard.set(c->device);
   if (argPtr) {
@@ -163,7 +164,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   if (c->nRanks == 1) {
     // One rank: a copy, or nothing when in place; pre-multiply ops still scale
     // (src/device/onerank.cu:55-90).
-    const bool scale = (a.coll != RA_COLL_ALLGATHER) && devOp == RA_OP_PREMULSUM;
+    const bool scale = reduces && devOp == RA_OP_PREMULSUM;
     if (a.send == a.recv && !scale) return ncclSuccess;
     const void* srcs[1] = {a.send};
     const size_t bytes = a.count * es;
@@ -182,6 +183,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.send = (const char*)a.send; w.recv = (char*)a.recv; w.count = a.count;
   w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg;
   w.stepBytes = (uint32_t)(p.chunkElems * es);
+  w.root = a.root;
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e = p.proto == 1 ? raLaunchLL(c->devComm, w, a.dtype, devOp, a.stream)
@@ -194,14 +196,21 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
   // src/misc/argcheck.cc:45-84
   RA_CHECK(raCommCheck(a.comm, name));
   if (a.dtype < 0 || a.dtype >= ncclNumTypes) { RA_WARN("%s: invalid type %d", name, a.dtype); return ncclInvalidArgument; }
-  if (a.coll != RA_COLL_ALLGATHER) {
+  if (a.coll != RA_COLL_ALLGATHER && a.coll != RA_COLL_BROADCAST) {
     if (a.op < 0 || (a.op >= ncclNumOps && (a.op - ncclNumOps >= RA_MAX_USER_OPS || !a.comm->userOps[a.op - ncclNumOps].used))) {
       RA_WARN("%s: invalid reduction operation %d", name, a.op);
       return ncclInvalidArgument;
     }
   }
+  if (a.coll == RA_COLL_BROADCAST || a.coll == RA_COLL_REDUCE) {
+    if (a.root < 0 || a.root >= a.comm->nRanks) { RA_WARN("%s: invalid root %d (root should be in the 0..%d range)", name, a.root, a.comm->nRanks); return ncclInvalidArgument; }
+    if (a.comm->nRanks > RA_MAX_SRCS) { RA_WARN("%s: supported up to %d ranks", name, RA_MAX_SRCS); return ncclInvalidUsage; }
+  }
   if (a.count == 0) return ncclSuccess;
-  if (a.send == nullptr || a.recv == nullptr) { RA_WARN("%s: sendbuff/recvbuff is NULL", name); return ncclInvalidArgument; }
+  // sendbuff may be NULL off the root of a broadcast, recvbuff off the root of a reduce (nccl.h.in:444,488)
+  const bool needSend = !(a.coll == RA_COLL_BROADCAST && a.comm->rank != a.root);
+  const bool needRecv = !(a.coll == RA_COLL_REDUCE && a.comm->rank != a.root);
+  if ((needSend && a.send == nullptr) || (needRecv && a.recv == nullptr)) { RA_WARN("%s: sendbuff/recvbuff is NULL", name); return ncclInvalidArgument; }
   return ncclSuccess;
 }
 
@@ -217,6 +226,7 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   const size_t es = raTypeSize(dtype);
   if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
   int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
+  if (coll == RA_COLL_BROADCAST || coll == RA_COLL_REDUCE) algo = RA_ALGO_DIRECT;   // one hop from / to the root
   if (algo == RA_ALGO_TREE && coll != RA_COLL_ALLREDUCE) algo = RA_ALGO_RING;   // no chain schedule for these two
   if (algo == RA_ALGO_DIRECT && n > RA_MAX_SRCS) algo = RA_ALGO_RING;
   p->algo = algo;
@@ -311,7 +321,7 @@ ncclResult_t raGroupEnd() {
 }
 
 ncclResult_t raEnqueue(const RaCollArgs& a) {
-  static const char* names[] = {"AllReduce", "ReduceScatter", "AllGather"};
+  static const char* names[] = {"AllReduce", "ReduceScatter", "AllGather", "Broadcast", "Reduce"};
   ncclResult_t r = checkArgs(a, names[a.coll]);
   if (r == ncclSuccess && a.comm) {
     r = raCommPollError(a.comm);

@@ -7,7 +7,8 @@ __global__ __launch_bounds__(1024) void raGatherKernel(const RaDevComm* __restri
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
   cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
-  if (w.algo == RA_ALGO_DIRECT) directAllGather(cx, w, role);
+  if (w.coll == RA_COLL_BROADCAST) directBroadcast(cx, w, role);
+  else if (w.algo == RA_ALGO_DIRECT) directAllGather(cx, w, role);
   else ringAllGather(cx, w);
   cx.finish();
 }
@@ -20,7 +21,7 @@ RA_DECL(0) RA_DECL(1) RA_DECL(2) RA_DECL(3) RA_DECL(4) RA_DECL(5) RA_DECL(6) RA_
 #undef RA_DECL
 
 hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int op, int grid, int block, hipStream_t s) {
-  if (w.coll == RA_COLL_ALLGATHER) {
+  if (w.coll == RA_COLL_ALLGATHER || w.coll == RA_COLL_BROADCAST) {
     hipLaunchKernelGGL(raGatherKernel, dim3(grid), dim3(block), 0, s, comm, w);
     return hipGetLastError();
   }

@@ -614,9 +614,16 @@ struct Ctx {
     drainVmem();       // every wave: its loads have returned and its stores are acknowledged
     __syncthreads();
     if (tid < 64) {
-      // Window data went out as system-scope write-through stores and every wave drained them before the
-      // barrier above, so no cache write-back is needed here (tuneFlags bit 0 adds a full release fence back).
-      if (sendMask && (comm->tuneFlags & 1)) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); drainVmem(); }
+      // Release before the flag.  Window data is written with system-scope write-through stores and every
+      // wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of the flag
+      // store; the fence adds the L2 write-back the reference also performs before posting a step on GFX9
+      // (prims_simple.h:168-171).  It costs about 0.5 ms of a 2.3 ms two-rank 1 GiB loop-back all-reduce and
+      // nothing measurable once a link is the bound.  tuneFlags 1 = no fence, 4 = system scope.
+      if (sendMask && !(comm->tuneFlags & 1)) {
+        if (comm->tuneFlags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        drainVmem();
+      }
       if (tid < RA_MAX_RANKS) {
         if (recvMask >> tid & 1) {          // slot consumed: credit to the sender (its window)
           const uint64_t s = sh->recvStep[tid][rk] + 1;
@@ -805,6 +812,69 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
           pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = w.recv + (size_t)p * nbytes + off;
         }
         pairCopyWG(pa, nb, cx.tid, cx.nthr);
+      });
+    }
+  }
+}
+
+// Broadcast (bytes): the root spreads each chunk into every peer's window (and into its own recvbuff
+// when out of place); every other rank copies what arrives from the root.  Role of
+// src/device/broadcast.h on the all-pairs links: one hop from the root to everybody.
+__device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks, r = cx.rank, root = w.root;
+  const uint32_t peers = peersMask(n, r);
+  const size_t nbytes = w.count * w.elemSize;
+  const size_t chunkB = w.chunkElems * w.elemSize;
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  if ((role == 0) != (r == root)) return;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * chunkB;
+    const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    if (role == 0) {
+      cx.step(0, 0, peers, 1, [&]() {
+        RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+        a.src[0] = w.send + off;
+        int k = 0;
+        if (w.recv != w.send) a.dst[k++] = w.recv + off;
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
+        a.nd = k;
+        copyWG(a, nb, cx.tid, cx.nthr);
+      });
+    } else {
+      cx.step(1u << root, 1, 0, 0, [&]() {
+        RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+        a.src[0] = cx.recvSlot(root, 1); a.dst[0] = w.recv + off;
+        copyWG(a, nb, cx.tid, cx.nthr);
+      });
+    }
+  }
+}
+
+// Reduce to a root: every other rank pushes its input into the root's window; the root folds the n
+// contributions in rank order (role of src/device/reduce.h, one hop).
+template <typename T, int OP>
+__device__ void directReduce(Ctx& cx, const RaWork& w, int role) {
+  const int n = cx.nRanks, r = cx.rank, root = w.root;
+  const uint32_t peers = peersMask(n, r);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
+  if ((role == 1) != (r == root)) return;
+  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const size_t off = g * w.chunkElems;
+    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    if (role == 0) {
+      cx.step(0, 0, 1u << root, 0, [&]() {
+        RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+        a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(root, 0); a.sysMask |= 1u << 0;
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      });
+    } else {
+      cx.step(peers, 0, 0, 0, [&]() {
+        RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
+        for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
+        a.dst[0] = (char*)(out + off);
+        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
   }
@@ -1138,6 +1208,7 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   if (w.algo == RA_ALGO_DIRECT) {
     if (w.coll == RA_COLL_ALLREDUCE) directAllReduce<T, OP>(cx, w, role);
     else if (w.coll == RA_COLL_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);
+    else if (w.coll == RA_COLL_REDUCE) directReduce<T, OP>(cx, w, role);
   } else if (w.algo == RA_ALGO_RING) {
     if (w.coll == RA_COLL_ALLREDUCE) ringAllReduce<T, OP>(cx, w);
     else if (w.coll == RA_COLL_REDUCESCATTER) ringReduceScatter<T, OP>(cx, w);

@@ -208,6 +208,14 @@ class Communicator:
         _check(lib().ncclAllGather(_ptr(sendbuff), _ptr(recvbuff), sendcount, datatype, self.handle, _stream(stream)),
                "ncclAllGather")
 
+    def broadcast(self, sendbuff, recvbuff, count, datatype, root, stream=None):
+        _check(lib().ncclBroadcast(_ptr(sendbuff), _ptr(recvbuff), count, datatype, root, self.handle, _stream(stream)),
+               "ncclBroadcast")
+
+    def reduce(self, sendbuff, recvbuff, count, datatype, op, root, stream=None):
+        _check(lib().ncclReduce(_ptr(sendbuff), _ptr(recvbuff), count, datatype, op, root, self.handle, _stream(stream)),
+               "ncclReduce")
+
     def create_premul_sum(self, scalar_bytes, datatype, residence=ncclScalarHostImmediate, device_ptr=None):
         """ncclRedOpCreatePreMulSum; scalar_bytes holds the scalar in `datatype`."""
         op = ctypes.c_int()

@@ -97,7 +97,13 @@ def check(dt, got_bytes, want, exact=True):
             bad = np.nonzero(got.view(np.uint8).reshape(-1, want.dtype.itemsize) !=
                              want.view(np.uint8).reshape(-1, want.dtype.itemsize))[0]
             i = int(bad[0])
-            return f"first bit mismatch at element {i} of {want.size}: got {got[i]!r}, want {want[i]!r} ({bad.size} byte diffs)"
+            elems = np.unique(bad)
+            cut = np.nonzero(np.diff(elems) != 1)[0]
+            starts = np.concatenate(([elems[0]], elems[cut + 1]))
+            ends = np.concatenate((elems[cut], [elems[-1]]))
+            runs = ", ".join(f"{int(a)}-{int(b)}" for a, b in list(zip(starts, ends))[:12])
+            return (f"first bit mismatch at element {i} of {want.size}: got {got[i]!r}, want {want[i]!r} ({bad.size} byte diffs, "
+                    f"{elems.size} elements in {starts.size} runs: {runs}; got {got[elems[:6]].tolist()} want {want[elems[:6]].tolist()})")
         return None
     i = orc.first_mismatch(dt, got, want)
     if i >= 0:

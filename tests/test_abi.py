@@ -49,9 +49,10 @@ def test_null_communicator_is_invalid_argument():
 
 def test_out_of_scope_entry_points_say_so():
     L = ra.lib()
-    assert L.ncclBroadcast(None, None, 0, 0, 0, None, None) == ra.ncclInvalidUsage
-    assert L.ncclReduce(None, None, 0, 0, 0, 0, None, None) == ra.ncclInvalidUsage
+    assert L.ncclSend(None, 0, 0, 0, None, None) == ra.ncclInvalidUsage
+    assert L.ncclRecv(None, 0, 0, 0, None, None) == ra.ncclInvalidUsage
     assert b"outside" in L.ncclGetLastError(None)
+    assert L.ncclBroadcast(None, None, 0, 0, 0, None, None) == ra.ncclInvalidArgument   # on the path: NULL comm
 
 
 def test_unique_ids_differ():

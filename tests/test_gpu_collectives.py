@@ -15,7 +15,7 @@ import pytest
 
 import expected as ex
 import oracle as orc
-from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_REDUCESCATTER, TestBed
+from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_BROADCAST, COLL_REDUCE, COLL_REDUCESCATTER, TestBed
 
 pytestmark = pytest.mark.gpu
 
@@ -140,6 +140,28 @@ def test_all_gather_cases(bed, algo):
         want = orc.all_gather_expected(ins)
         for r in range(n):
             assert ex.check(dt, outs[r], want, exact=True) is None, (orc.DT_NAMES[dt], count, in_place, r)
+
+
+def test_broadcast_and_reduce(bed):
+    """ncclBroadcast / ncclReduce (expected values as test/common/PrepDataFuncs.cpp:43-78 and :80-148):
+    every rank ends with the root's pattern; the root ends with the rank-order fold."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n = bed.nranks
+    for root in (0, n - 1):
+        for dt, count, in_place in ((orc.F32, 1048576, False), (orc.F16, 53327, False), (orc.I8, 1000003, True), (orc.F64, 4099, False)):
+            ins = [orc.fill_pattern(dt, count, root if r == root else 200 + r) for r in range(n)]   # only the root's input counts
+            outs = bed.run(COLL_BROADCAST, dt, orc.SUM, count, ins, count * _es(dt), in_place=in_place, root=root)
+            for r in range(n):
+                assert ex.check(dt, outs[r], ins[root], exact=True) is None, (root, orc.DT_NAMES[dt], count, r)
+        for dt, op, count in ((orc.F32, orc.SUM, 1048576), (orc.I32, orc.PROD, 384), (orc.BF16, orc.MAX, 53327), (orc.U64, orc.AVG, 70001),
+                              (orc.F32, orc.AVG, 70001)):
+            ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+            outs = bed.run(COLL_REDUCE, dt, op, count, ins, count * _es(dt), root=root)
+            assert ex.check(dt, outs[root], orc.device_fold(dt, op, ins), exact=True) is None, (root, orc.DT_NAMES[dt], orc.OP_NAMES[op])
+            assert ex.check(dt, outs[root], orc.host_fold(dt, op, ins), exact=False) is None
+            for r in range(n):
+                if r != root:      # recvbuff of the other ranks is left alone
+                    assert (outs[r] == 0xA5).all()
 
 
 def test_back_to_back_and_reinit(bed):

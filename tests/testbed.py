@@ -15,7 +15,7 @@ import traceback
 
 import numpy as np
 
-COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER = 0, 1, 2
+COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE = 0, 1, 2, 3, 4
 
 
 def _child(rank, nranks, device, conn, env):
@@ -59,25 +59,38 @@ def _child(rank, nranks, device, conn, env):
             elif cmd == "coll":
                 # args: dict(coll, dtype, op, count, input(np bytes), out_bytes, in_place, premul(bytes|None), iters)
                 a = args
-                inp = torch.from_numpy(np.frombuffer(a["input"], dtype=np.uint8).copy()).cuda()
                 es = ra.TYPE_SIZE[a["dtype"]]
+                host_in = np.frombuffer(a["input"], dtype=np.uint8)
+
+                def upload(image):
+                    """One host-to-device copy per buffer, read back before use.  (A device-side fill followed by a
+                    device copy over it was seen to leave whole cache lines of the fill value behind on some boxes
+                    when several processes share the GPU; tools/torch_fill_copy_probe.py is the stand-alone probe.)"""
+                    for attempt in range(2):
+                        t = torch.from_numpy(image).cuda()
+                        torch.cuda.synchronize()
+                        if np.array_equal(t.cpu().numpy(), image):
+                            return t
+                        print(f"testbed rank {rank}: an uploaded buffer read back differently (attempt {attempt})", flush=True)
+                    raise RuntimeError("test bed: a host-to-device upload does not read back as written")
+
                 if a["in_place"]:
                     # buffer sized for the larger side; input placed where the API expects it
-                    nbytes = max(len(a["input"]), a["out_bytes"])
-                    buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+                    nbytes = max(host_in.size, a["out_bytes"])
+                    image = np.zeros(nbytes, dtype=np.uint8)
+                    off = rank * a["count"] * es if a["coll"] == COLL_ALLGATHER else 0
+                    image[off:off + host_in.size] = host_in
+                    buf = upload(image)
                     if a["coll"] == COLL_ALLGATHER:
-                        off = rank * a["count"] * es
-                        buf[off:off + len(a["input"])] = inp
                         send_ptr, recv_ptr = buf.data_ptr() + off, buf.data_ptr()
                     elif a["coll"] == COLL_REDUCESCATTER:
-                        buf[:len(a["input"])] = inp
                         send_ptr, recv_ptr = buf.data_ptr(), buf.data_ptr() + rank * a["count"] * es
                     else:
-                        buf[:len(a["input"])] = inp
                         send_ptr = recv_ptr = buf.data_ptr()
                     out_view = lambda: buf
                 else:
-                    out = torch.full((a["out_bytes"],), 0xA5, dtype=torch.uint8, device="cuda")
+                    inp = upload(host_in.copy())
+                    out = upload(np.full(a["out_bytes"], 0xA5, dtype=np.uint8))
                     send_ptr, recv_ptr = inp.data_ptr(), out.data_ptr()
                     out_view = lambda: out
                 op = a["op"]
@@ -92,6 +105,10 @@ def _child(rank, nranks, device, conn, env):
                         comm.all_reduce(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
                     elif a["coll"] == COLL_REDUCESCATTER:
                         comm.reduce_scatter(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
+                    elif a["coll"] == COLL_BROADCAST:
+                        comm.broadcast(send_ptr, recv_ptr, a["count"], a["dtype"], a["root"], stream)
+                    elif a["coll"] == COLL_REDUCE:
+                        comm.reduce(send_ptr, recv_ptr, a["count"], a["dtype"], op, a["root"], stream)
                     else:
                         comm.all_gather(send_ptr, recv_ptr, a["count"], a["dtype"], stream)
 
@@ -111,12 +128,7 @@ def _child(rank, nranks, device, conn, env):
                     for _ in range(0 if a.get("graph") else a.get("iters", 1)):
                         if a["in_place"] and a.get("iters", 1) > 1:
                             raise ValueError("in-place with iters>1 would re-reduce its own output")
-                        if a["coll"] == COLL_ALLREDUCE:
-                            comm.all_reduce(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
-                        elif a["coll"] == COLL_REDUCESCATTER:
-                            comm.reduce_scatter(send_ptr, recv_ptr, a["count"], a["dtype"], op, stream)
-                        else:
-                            comm.all_gather(send_ptr, recv_ptr, a["count"], a["dtype"], stream)
+                        issue()
                 stream.synchronize()
                 if user_op is not None:
                     comm.destroy_op(user_op)
@@ -194,13 +206,13 @@ class TestBed:
         return info
 
     def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False,
-            skip_ranks=(), expect_errors=False):
+            skip_ranks=(), expect_errors=False, root=0):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                      out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
-                     graph=graph, skip=r in skip_ranks)
+                     graph=graph, skip=r in skip_ranks, root=root)
                 for r in range(self.nranks)]
         res = self._all("coll", args)
         if expect_errors:
