@@ -21,6 +21,11 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     a = ap.parse_args()
+    if a.ranks > 2:
+        # every rank's kernel must be running at once; a process gets 4 hardware queues per GPU (GPU_MAX_HW_QUEUES)
+        # and streams share them, so with more ranks one rank's kernel can queue behind a kernel that waits for it
+        sys.exit("more than 2 ranks inside one process on one GPU can deadlock on shared hardware queues; "
+                 "use bench.py under torch.distributed.run (one process per rank) for more")
     os.environ["RCCL_AMD_MULTI_RANK_GPU"] = "1"
     os.environ.setdefault("RCCL_AMD_SPIN_TIMEOUT_MS", "20000")
     os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // a.ranks)))
