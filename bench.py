@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--coll", default="allreduce", choices=["allreduce", "reducescatter", "allgather"])
     ap.add_argument("--in-place", action="store_true")
+    ap.add_argument("--register", action="store_true",
+                    help="ncclCommRegister the receive buffer first (zero-copy gather phase); off in the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU baseline sample")
     return ap.parse_args()
@@ -106,6 +108,10 @@ def main():
     sendbuf = (torch.rand(in_elems, device="cuda", generator=gen, dtype=torch.float32) * 2 - 1).to(tdt)
     recvbuf = sendbuf if (args.in_place and args.coll == "allreduce") else torch.zeros(out_elems, device="cuda", dtype=tdt)
     stream = torch.cuda.current_stream()
+    reg_handle = None
+    if args.register and n > 1:
+        reg_handle = comm.register(recvbuf.data_ptr(), recvbuf.numel() * recvbuf.element_size())
+        barrier()                                       # every rank's registration is published before the first launch
 
     def step():
         if args.coll == "allreduce":
@@ -191,6 +197,7 @@ def main():
                                f"{S} B per rank, out-of-place, device-resident random bucket"
                                + ("" if n > 1 else " (1 rank: the reference path is a device copy; value is its S/t)"),
                    "ranks": n, "ranks_per_gpu": (n + ndev - 1) // ndev, "algbw_GBps": round(algbw, 3),
+                   "registered_recvbuff": bool(reg_handle), "gather_phase_pieces": comm.stats() if n > 1 else None,
                    "plan": comm.plan_info(0 if args.coll == "allreduce" else 1 if args.coll == "reducescatter" else 2,
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,
@@ -222,6 +229,8 @@ def main():
                                           f"buckets ran at {round(S / 8 / c8 / 1e9, 3)} GB/s of output",
                                 "host_cpus": os.cpu_count()}
 
+    if reg_handle:
+        comm.deregister(reg_handle)
     comm.destroy()
     if n > 1:
         dist.barrier()

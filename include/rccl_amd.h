@@ -103,6 +103,11 @@ ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device);           /* 
 ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);             /* nccl.h.in:317 */
 ncclResult_t ncclMemAlloc(void** ptr, size_t size);                          /* nccl.h.in:105 */
 ncclResult_t ncclMemFree(void* ptr);                                         /* nccl.h.in:108 */
+/* Registers a device buffer with the communicator; local call, reference-counted per allocation
+ * (src/register.cc:106-160).  An all-reduce whose recvbuff lies in a registered allocation on a rank
+ * lets the other ranks write their finished pieces straight into it instead of through the FIFO. */
+ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle);   /* nccl.h.in:324 */
+ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle);                           /* nccl.h.in:330 */
 
 /* ---- custom pre-multiply-sum operator --------------------------------------- */
 ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype,
@@ -177,6 +182,10 @@ ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll,
 ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo,
                                   int maxChannels, size_t slotBytes, size_t minChunkBytes, int* algoOut,
                                   int* nChannels, size_t* chunkElems, size_t* lastChunkElems, int* grid);
+
+/* Counters of the all-reduce gather phase on this rank since the communicator was created: pieces written
+ * straight into a peer's registered receive buffer, and pieces sent through the FIFO.  Synchronous. */
+ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces);
 
 /* Rendezvous check without a GPU: joins the endpoint named by `id` as `rank` of `nranks`, all-gathers
  * `bytes` bytes per rank into `all`, and leaves.  It is the exchange ncclCommInitRank performs for the

@@ -6,6 +6,7 @@
 #include "comm.h"
 #include "debug.h"
 #include "launch.h"
+#include "reg.h"
 
 #define RA_API extern "C" __attribute__((visibility("default")))
 
@@ -106,6 +107,30 @@ RA_API ncclResult_t ncclMemAlloc(void** ptr, size_t size) {
 }
 RA_API ncclResult_t ncclMemFree(void* ptr) {
   RA_HIP(hipFree(ptr));
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle) {
+  RA_CHECK(raCommCheck(comm, "ncclCommRegister"));       // src/register.cc:154-160
+  return raRegRegister(comm, buff, size, handle);
+}
+RA_API ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle) {
+  RA_CHECK(raCommCheck(comm, "ncclCommRegister"));       // (sic) src/register.cc:163-164
+  return raRegDeregister(comm, handle);
+}
+RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces) {
+  RA_CHECK(raCommCheck(comm, "rcclAmdCommStats"));
+  uint64_t v[2] = {0, 0};
+  if (comm->stats) {
+    int old = 0;
+    (void)hipGetDevice(&old);
+    (void)hipSetDevice(comm->device);
+    hipError_t e = hipMemcpy(v, comm->stats, sizeof v, hipMemcpyDeviceToHost);
+    (void)hipSetDevice(old);
+    if (e != hipSuccess) return ncclUnhandledCudaError;
+  }
+  if (directPieces) *directPieces = v[0];
+  if (fifoPieces) *fifoPieces = v[1];
   return ncclSuccess;
 }
 

@@ -18,6 +18,7 @@
 
 #include "debug.h"
 #include "net.h"
+#include "reg.h"
 #include "topo.h"
 
 namespace {
@@ -142,6 +143,10 @@ ncclResult_t buildDevComm(ncclComm* c) {
   RA_HIP(hipMemset(c->steps, 0, 2 * nSteps * sizeof(uint64_t)));
   RA_HIP(hipMalloc((void**)&c->llEpoch, RA_LL_GRID * sizeof(uint32_t)));
   RA_HIP(hipMemset(c->llEpoch, 0, RA_LL_GRID * sizeof(uint32_t)));
+  RA_HIP(hipMalloc((void**)&c->regTable, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
+  RA_HIP(hipMemset(c->regTable, 0, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
+  RA_HIP(hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t)));
+  RA_HIP(hipMemset(c->stats, 0, 8 * sizeof(uint64_t)));
   RA_HIP(hipHostMalloc((void**)&c->hostFlags, 64, hipHostMallocMapped));
   memset(c->hostFlags, 0, 64);
   RA_HIP(hipHostGetDevicePointer((void**)&c->hostFlagsDev, c->hostFlags, 0));
@@ -163,6 +168,8 @@ ncclResult_t buildDevComm(ncclComm* c) {
   long ms = envLong("RCCL_AMD_SPIN_TIMEOUT_MS", 120000);
   if (ms < 1) ms = 1;
   h.timeoutTicks = (uint64_t)ms * 100000ull;
+  h.regTable = c->regTable;
+  h.stats = c->stats;
   h.netMode = c->net ? 1u : 0u;
   h.tuneFlags = (uint32_t)envLong("RCCL_AMD_TUNE_FLAGS", 0);
   h.nRings = c->nRings;
@@ -194,7 +201,10 @@ void freeLocal(ncclComm* c) {
   if (c->devComm) (void)hipFree(c->devComm);
   if (c->steps) (void)hipFree(c->steps);
   if (c->llEpoch) (void)hipFree(c->llEpoch);
-  c->llEpoch = nullptr;
+  if (c->regTable) (void)hipFree(c->regTable);
+  if (c->stats) (void)hipFree(c->stats);
+  c->llEpoch = nullptr; c->regTable = nullptr; c->stats = nullptr;
+  raRegShutdown(c);
   if (c->hostFlags) (void)hipHostFree(c->hostFlags);
   if (c->orderEvent) (void)hipEventDestroy(c->orderEvent);
   c->devComm = nullptr; c->steps = nullptr; c->hostFlags = nullptr; c->orderEvent = nullptr;
@@ -253,6 +263,7 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
   clique->nRanks = ndev;
   clique->window.assign((size_t)ndev, nullptr);
   clique->device = devs;
+  const uint64_t regKey = raRegLocalKey();
   std::vector<ncclComm*> cs((size_t)ndev, nullptr);
   ncclResult_t res = ncclSuccess;
   for (int i = 0; i < ndev && res == ncclSuccess; i++) {
@@ -263,6 +274,7 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
     if (hipSetDevice(c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
     res = allocWindow(c);
     clique->window[(size_t)i] = c->window;
+    if (res == ncclSuccess) res = raRegInit(c, regKey);
   }
   for (int i = 0; i < ndev && res == ncclSuccess; i++) {
     ncclComm* c = cs[(size_t)i];
@@ -322,6 +334,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
     if (nranks == 1) {
       makeLayout(c);
       c->clique = std::make_shared<RaClique>();
+      if ((res = raRegInit(c, key)) != ncclSuccess) break;
       res = buildDevComm(c);
       break;
     }
@@ -333,6 +346,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       makeLayout(c);
       c->clique = std::make_shared<RaClique>();
       if ((res = raNetSetup(c)) != ncclSuccess) break;
+      if ((res = raRegInit(c, key)) != ncclSuccess) break;
       if ((res = buildDevComm(c)) != ncclSuccess) break;
       res = c->boot.barrier();
       break;
@@ -384,6 +398,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       }
     }
     if (res != ncclSuccess) break;
+    if ((res = raRegInit(c, key)) != ncclSuccess) break;
     if ((res = buildDevComm(c)) != ncclSuccess) break;
     res = c->boot.barrier();      // nobody launches before every window is mapped everywhere
   } while (0);

@@ -27,6 +27,7 @@ struct RaClique {
 };
 
 struct RaNet;
+struct RaRegState;
 
 struct RaUserOp {
   bool used = false;
@@ -57,6 +58,9 @@ struct ncclComm {
   uint32_t* llEpoch = nullptr;       // per low-latency workgroup launch counters (device)
   uint32_t* hostFlags = nullptr;     // pinned, mapped: [0] abort request, [1] device error
   uint32_t* hostFlagsDev = nullptr;
+  RaRegSlot* regTable = nullptr;     // device copy of the peers' registered allocations as mapped here
+  uint64_t* stats = nullptr;         // device counters (RaDevComm::stats)
+  RaRegState* reg = nullptr;         // registration cache and boards (reg.cc)
   int nRings = 0;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
 

@@ -72,6 +72,19 @@ __host__ __device__ inline size_t raLLOffset(const RaWindowLayout& l, int buf, i
   return l.llOffset + ((size_t)buf * l.nRanks + sender) * l.llBytes;
 }
 
+// Registered receive buffers (zero-copy gather of the all-pairs all-reduce).  A rank announces which of its
+// registrations its receive buffer lies in with one word: valid bit, board entry, entry serial, byte offset.
+#define RA_MAX_REGS 32
+struct RaRegSlot { uint64_t base; uint64_t serial; };   // a peer's registered allocation as mapped HERE; base 0 = not mapped
+#define RA_REG_VALID (1ull << 63)
+__host__ __device__ inline uint64_t raRegWord(int idx, uint32_t serial, uint64_t off) {
+  return RA_REG_VALID | ((uint64_t)(idx & 63) << 57) | ((uint64_t)(serial & 0xffffu) << 41) | (off & ((1ull << 41) - 1));
+}
+#define RA_REG_IDX(w) ((int)(((w) >> 57) & 63))
+#define RA_REG_SERIAL(w) (((w) >> 41) & 0xffffu)
+#define RA_REG_OFF(w) ((w) & ((1ull << 41) - 1))
+#define RA_AUX_DIRECT 0xD1D1D1D1D1D1D1D1ull   // "this launch's pieces were written into your receive buffer"
+
 struct RaDevComm {
   int rank;
   int nRanks;
@@ -84,6 +97,8 @@ struct RaDevComm {
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
   uint32_t netMode;           // 1: windows are host-pinned staging areas pumped over TCP by a proxy thread
+  const RaRegSlot* regTable;  // [RA_MAX_RANKS][RA_MAX_REGS]
+  uint64_t* stats;            // [0] pieces written straight into a peer's receive buffer, [1] pieces sent through the FIFO (all-reduce gather phase)
   uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = no release fence, 2 = no acquire fence (breaks results), 4 = system-scope release
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
@@ -103,4 +118,6 @@ struct RaWork {
   uint64_t opArg;      // PreMulSum scalar bits / SumPostDiv divisor
   uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
   int root;            // broadcast / reduce
+  uint64_t regWord;    // announce word for recv (0: not registered)
+  int peerRegs;        // some peer registration is mapped on this rank: read the peers' announce words
 };

@@ -15,6 +15,7 @@
 #include "comm.h"
 #include "debug.h"
 #include "launch.h"
+#include "reg.h"
 
 size_t raTypeSize(int dt) {
   switch (dt) {
@@ -184,6 +185,8 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg;
   w.stepBytes = (uint32_t)(p.chunkElems * es);
   w.root = a.root;
+  if (a.coll == RA_COLL_ALLREDUCE && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net)
+    RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e = p.proto == 1 ? raLaunchLL(c->devComm, w, a.dtype, devOp, a.stream)

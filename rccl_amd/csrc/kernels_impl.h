@@ -520,6 +520,11 @@ struct ChanShared {
   uint32_t sendDirty[RA_NKINDS];
   uint32_t recvDirty[RA_NKINDS];
   int aborted;
+  // Registered receive buffers: the word each peer sent with the first step of its FIFO in this launch, the word
+  // this workgroup sends with its own first post, and where a peer's receive buffer is mapped here (0: use the FIFO).
+  uint64_t auxIn[RA_MAX_RANKS];
+  uint64_t auxOut[RA_MAX_RANKS];
+  uint64_t directBase[RA_MAX_RANKS];
 };
 
 struct Ctx {
@@ -527,6 +532,7 @@ struct Ctx {
   ChanShared* sh;
   int ch, tid, nthr, rank, nRanks;
   uint32_t stepBytes;
+  int auxRecv = 0, auxSend = 0;   // this step carries the once-per-launch words (first step of a workgroup only)
 
   __device__ __forceinline__ uint64_t* flag(int owner, int which, int peer, int kind) const {
     return (uint64_t*)(comm->win[owner] + raFlagOffset(comm->lay, which, ch, peer, kind));
@@ -555,6 +561,7 @@ struct Ctx {
       sh->aborted = 0;
       for (int k = 0; k < RA_NKINDS; k++) { sh->sendDirty[k] = 0; sh->recvDirty[k] = 0; }
     }
+    if (tid < RA_MAX_RANKS) { sh->auxIn[tid] = 0; sh->auxOut[tid] = 0; sh->directBase[tid] = 0; }
     __syncthreads();
   }
   // Persist the step counters this workgroup advanced.
@@ -598,6 +605,7 @@ struct Ctx {
     if (tid < RA_MAX_RANKS) {
       if (recvMask >> tid & 1) {
         spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
+        if (auxRecv) sh->auxIn[tid] = ldFlag(flag(rank, 2 + (int)(sh->recvStep[tid][rk] % comm->lay.nSlots), tid, rk));
         if (!(comm->tuneFlags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
       }
     } else if (tid < 2 * RA_MAX_RANKS) {
@@ -638,6 +646,10 @@ struct Ctx {
           if (ok) {
             // host-staged transport: tell the proxy how many bytes this slot carries, then publish
             if (comm->netMode) stFlag(flag(p, 2 + (int)((s - 1) % comm->lay.nSlots), rank, sk), stepBytes);
+            else if (auxSend) {               // the word must be in place before the tail that announces it
+              stFlag(flag(p, 2 + (int)((s - 1) % comm->lay.nSlots), rank, sk), sh->auxOut[p]);
+              drainVmem();
+            }
             stFlag(flag(p, 0, rank, sk), s);
           }
         }
@@ -686,8 +698,16 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
+  // Registered receive buffers (zero-copy gather).  With its first scatter step every rank tells each peer whether
+  // and where its recvbuff is registered; a reducer that has that registration mapped writes its finished piece
+  // straight into the peer's recvbuff and says so with its first broadcast-phase post, and the peer's gather role
+  // then has nothing to copy for it.  The words travel beside the FIFO slots, once per launch and channel.
+  const bool words = !cx.comm->netMode;
+  if (role == 0 && cx.tid < n) cx.sh->auxOut[cx.tid] = w.regWord;
   for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
+    const bool first = g == (size_t)cx.ch;
     if (role == 0) {
+      cx.auxSend = words && first;
       cx.step(0, 0, peers, 0, [&]() {
         // all n-1 pieces in one fused pass when they have the same length and need no scaling
         RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
@@ -708,28 +728,60 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
         }
       });
     } else if (role == 1) {
+      cx.auxRecv = words && first && w.peerRegs;
+      cx.auxSend = words && first;
       cx.step(peers, 0, peers, 1, [&]() {
+        if (first && words) {
+          if (cx.tid < n && cx.tid != r) {
+            const int p = cx.tid;
+            const uint64_t W = w.peerRegs ? cx.sh->auxIn[p] : 0;
+            uint64_t base = 0;
+            if ((W & RA_REG_VALID) && RA_REG_IDX(W) < RA_MAX_REGS) {
+              const RaRegSlot slot = cx.comm->regTable[p * RA_MAX_REGS + RA_REG_IDX(W)];
+              if (slot.base && slot.serial == RA_REG_SERIAL(W)) base = slot.base + RA_REG_OFF(W);
+            }
+            cx.sh->directBase[p] = base;
+            cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
+          }
+          __syncthreads();
+        }
         size_t off, ne; R.piece(g, r, off, ne);
         RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
         for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
         a.dst[0] = (char*)(out + off);
-        int k = 1;
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
+        int k = 1, nDirect = 0;
+        for (int i = 1; i < n; i++) {
+          const int p = (r + i) % n;
+          const uint64_t base = cx.sh->directBase[p];
+          a.sysMask |= 1u << k;
+          a.dst[k++] = base ? (char*)base + off * sizeof(T) : cx.sendSlot(p, 1);
+          nDirect += base != 0;
+        }
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        if (cx.tid == 0) {
+          if (nDirect) __hip_atomic_fetch_add(&cx.comm->stats[0], (uint64_t)nDirect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (n - 1 - nDirect) __hip_atomic_fetch_add(&cx.comm->stats[1], (uint64_t)(n - 1 - nDirect), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       });
     } else {
+      cx.auxRecv = words && first && w.regWord != 0;
       cx.step(peers, 1, 0, 0, [&]() {
-        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
-        size_t ne0 = 0; bool same = true;
+        // pieces a peer wrote straight into recvbuff need no copy
+        RcArgs pa; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        size_t ne0 = 0; bool same = true; int np = 0;
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
+          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
           size_t off, ne; R.piece(g, p, off, ne);
-          if (i == 1) ne0 = ne; else same = same && ne == ne0;
-          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = (char*)(out + off);
+          if (np == 0) ne0 = ne; else same = same && ne == ne0;
+          pa.src[np] = cx.recvSlot(p, 1); pa.dst[np] = (char*)(out + off); np++;
         }
+        pa.ns = np; pa.nd = np;
+        if (np == 0) return;
         if (same) { pairCopyWG(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
+          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
           a.src[0] = cx.recvSlot(p, 1); a.dst[0] = (char*)(out + off);
@@ -738,6 +790,7 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
       });
     }
   }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers

@@ -30,6 +30,7 @@ EXPORTS = [
     "ncclGetVersion", "ncclGetErrorString", "ncclGetLastError", "ncclCommGetAsyncError", "ncclGetUniqueId",
     "ncclCommInitRankConfig", "ncclCommInitRank", "ncclCommInitAll", "ncclCommFinalize", "ncclCommDestroy",
     "ncclCommAbort", "ncclCommCount", "ncclCommCuDevice", "ncclCommUserRank", "ncclMemAlloc", "ncclMemFree",
+    "ncclCommRegister", "ncclCommDeregister", "rcclAmdCommStats",
     "ncclRedOpCreatePreMulSum", "ncclRedOpDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather",
     "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
     "ncclCommSplit", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
@@ -82,6 +83,9 @@ def lib():
             getattr(L, f).argtypes = [vp, ctypes.POINTER(ci)]
         L.ncclMemAlloc.argtypes = [ctypes.POINTER(vp), sz]
         L.ncclMemFree.argtypes = [vp]
+        L.ncclCommRegister.argtypes = [vp, vp, sz, ctypes.POINTER(vp)]
+        L.ncclCommDeregister.argtypes = [vp, vp]
+        L.rcclAmdCommStats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.ncclRedOpCreatePreMulSum.argtypes = [ctypes.POINTER(ci), vp, ci, ci, vp]
         L.ncclRedOpDestroy.argtypes = [ci, vp]
         L.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
@@ -237,6 +241,20 @@ class Communicator:
         _check(lib().rcclAmdPlanInfo(self.handle, coll, count, datatype, ctypes.byref(a), ctypes.byref(p),
                                      ctypes.byref(c), ctypes.byref(ch)), "rcclAmdPlanInfo")
         return {"algo": a.value, "proto": p.value, "nChannels": c.value, "chunkElems": ch.value}
+
+    def register(self, buff, size):
+        """ncclCommRegister: returns the opaque handle to pass to deregister()."""
+        h = ctypes.c_void_p()
+        _check(lib().ncclCommRegister(self.handle, _ptr(buff), size, ctypes.byref(h)), "ncclCommRegister")
+        return h.value
+
+    def deregister(self, handle):
+        _check(lib().ncclCommDeregister(self.handle, ctypes.c_void_p(handle)), "ncclCommDeregister")
+
+    def stats(self):
+        d, f = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().rcclAmdCommStats(self.handle, ctypes.byref(d), ctypes.byref(f)), "rcclAmdCommStats")
+        return {"direct_pieces": d.value, "fifo_pieces": f.value}
 
     def finalize(self):
         _check(lib().ncclCommFinalize(self.handle), "ncclCommFinalize")

@@ -221,6 +221,44 @@ def test_hip_graph_capture_and_replay(bed):
         assert ex.check(orc.F64, outs[r], orc.reduce_scatter_expected(orc.F64, orc.MAX, ins, r), exact=True) is None
 
 
+def test_registered_receive_buffers_are_written_directly(bed):
+    """ncclCommRegister (src/register.cc:154-185): with the receive buffer registered, the other ranks write their
+    finished all-reduce pieces straight into it (no broadcast-phase FIFO traffic, no gather copy); results are the
+    same bits as through the FIFO.  Mixed cases: only some ranks registered, in place, after deregistration."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n = bed.nranks
+    count = (1 << 20) + 24          # 4 MiB fp32: the FIFO protocol, several rounds on every channel
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    plan = bed.plan(COLL_ALLREDUCE, count, orc.F32)
+    assert plan["proto"] == 0 and plan["algo"] == ex.ALGO_DIRECT
+    want = ex.allreduce(orc.F32, orc.SUM, ins, plan)
+    # every rank registered: all pieces go direct, on the first launch already and on the second
+    for outs, stats in bed.run_registered(orc.F32, orc.SUM, count, ins, runs=2):
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+            assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    # only rank 0 registered: every other rank writes one of its n-1 pieces per round directly
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[0])
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+    assert stats[0]["direct_pieces"] == 0
+    for r in range(1, n):
+        assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == (n - 2) * stats[r]["direct_pieces"], (r, stats[r])
+    # in place, ragged bf16 count, average
+    c2 = 3 * 1024 * 1024 + 1000
+    ins2 = [orc.fill_pattern(orc.BF16, c2, r) for r in range(n)]
+    want2 = ex.allreduce(orc.BF16, orc.AVG, ins2, bed.plan(COLL_ALLREDUCE, c2, orc.BF16))
+    (outs, stats), = bed.run_registered(orc.BF16, orc.AVG, c2, ins2, in_place=True)
+    for r in range(n):
+        assert ex.check(orc.BF16, outs[r], want2, exact=True) is None, r
+        assert stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    # nothing registered any more: back to the FIFO, same bits
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[])
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+        assert stats[r]["direct_pieces"] == 0 and stats[r]["fifo_pieces"] > 0, (r, stats[r])
+
+
 def test_host_staged_tcp_transport(bed):
     """NCCL_P2P_DISABLE=1: every hop goes GPU -> pinned host -> loopback TCP -> pinned host -> GPU
     (the reference's socket transport, src/transport/net.cc + net_socket.cc).  Same kernels, same results."""

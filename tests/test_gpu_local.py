@@ -129,3 +129,44 @@ def test_argument_errors():
         assert ra.lib().ncclSend(None, 0, 0, 0, None, None) == ra.ncclInvalidUsage
     finally:
         comm.destroy()
+
+
+def test_register_cache_semantics():
+    """ncclCommRegister / ncclCommDeregister keep a reference-counted cache per allocation
+    (src/register.cc:106-136,163-185): a range inside a registered allocation returns the same handle,
+    the entry goes away with the last deregistration, an unknown handle is ncclInvalidUsage."""
+    import ctypes
+    import torch
+    import rccl_amd as ra
+    comm = ra.Communicator.init_all(1, [0])[0]
+    try:
+        t = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+        h1 = comm.register(t.data_ptr(), 4096)
+        h2 = comm.register(t.data_ptr() + 8192, 1000)          # same allocation: the same cache entry
+        assert h1 and h1 == h2
+        comm.deregister(h1)
+        comm.deregister(h2)
+        with pytest.raises(ra.NcclError) as e:
+            comm.deregister(h1)                                # gone with the last reference
+        assert e.value.code == ra.ncclInvalidUsage
+        with pytest.raises(ra.NcclError) as e:
+            comm.deregister(0x1234)
+        assert e.value.code == ra.ncclInvalidUsage
+        host = ctypes.create_string_buffer(4096)
+        with pytest.raises(ra.NcclError) as e:
+            comm.register(ctypes.addressof(host), 4096)        # not device memory
+        assert e.value.code == ra.ncclInvalidArgument
+        with pytest.raises(ra.NcclError) as e:
+            comm.register(t.data_ptr(), 0)
+        assert e.value.code == ra.ncclInvalidArgument
+        # registered buffers do not change the one-rank path
+        x = torch.arange(1000, dtype=torch.float32, device="cuda")
+        y = torch.zeros_like(x)
+        h = comm.register(y.data_ptr(), 4000)
+        comm.all_reduce(x, y, 1000, ra.ncclFloat32, ra.ncclSum)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        comm.deregister(h)
+        assert ra.lib().ncclCommRegister(None, None, 0, None) == ra.ncclInvalidArgument
+    finally:
+        comm.destroy()

@@ -141,6 +141,34 @@ def _child(rank, nranks, device, conn, env):
                     else:
                         res = res[:a["out_bytes"]]
                 conn.send(("ok", (err, res.tobytes())))
+            elif cmd == "reg_prepare":
+                # args: dict(dtype, count, input(bytes), in_place, register_recv): buffers that stay alive across commands
+                a = args
+                es = ra.TYPE_SIZE[a["dtype"]]
+                host_in = np.frombuffer(a["input"], dtype=np.uint8)
+                reg_in = torch.from_numpy(host_in.copy()).cuda()
+                reg_out = reg_in if a["in_place"] else torch.from_numpy(np.full(host_in.size, 0xA5, dtype=np.uint8)).cuda()
+                torch.cuda.synchronize()
+                reg_handle = comm.register(reg_out.data_ptr(), host_in.size) if a["register_recv"] else None
+                reg_state = (a, reg_in, reg_out, reg_handle)
+                conn.send(("ok", None))
+            elif cmd == "reg_run":
+                a, reg_in, reg_out, reg_handle = reg_state
+                before = comm.stats()
+                if not a["in_place"]:
+                    reg_out.fill_(0x5A)
+                    torch.cuda.synchronize()
+                comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                stream.synchronize()
+                after = comm.stats()
+                conn.send(("ok", (comm.async_error(), reg_out.cpu().numpy().tobytes(),
+                                  {k: after[k] - before[k] for k in after})))
+            elif cmd == "reg_release":
+                a, reg_in, reg_out, reg_handle = reg_state
+                if reg_handle is not None:
+                    comm.deregister(reg_handle)
+                reg_state = None
+                conn.send(("ok", None))
             elif cmd == "plan":
                 conn.send(("ok", comm.plan_info(*args)))
             elif cmd == "destroy":
@@ -220,6 +248,25 @@ class TestBed:
         for r, (err, _) in enumerate(res):
             assert err == 0, f"rank {r}: asynchronous error {err}"
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
+
+    def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1):
+        """All-reduce on buffers that stay allocated (and registered on `register_ranks`, default all) across `runs`
+        launches.  Returns, per run, (outputs per rank, stats deltas per rank)."""
+        if not self.inited:
+            self.init_comms()
+        regs = set(range(self.nranks)) if register_ranks is None else set(register_ranks)
+        self._all("reg_prepare", [dict(dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
+                                       in_place=in_place, register_recv=r in regs) for r in range(self.nranks)])
+        results = []
+        for _ in range(runs):
+            res = self._all("reg_run", [None] * self.nranks)
+            for r, (err, _, _) in enumerate(res):
+                assert err == 0, f"rank {r}: asynchronous error {err}"
+            results.append(([np.frombuffer(b, dtype=np.uint8) for _, b, _ in res], [st for _, _, st in res]))
+            if in_place:
+                break          # a second in-place run would reduce the first one's output
+        self._all("reg_release", [None] * self.nranks)
+        return results
 
     def command(self, rank, cmd, args=None):
         self.conns[rank].send((cmd, args))

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=1 << 30)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--register", action="store_true", help="register the receive buffers (zero-copy gather phase)")
     a = ap.parse_args()
     if a.ranks > 2:
         # every rank's kernel must be running at once; a process gets 4 hardware queues per GPU (GPU_MAX_HW_QUEUES)
@@ -37,6 +38,7 @@ def main():
     ins = [torch.rand(count, device="cuda") for _ in range(n)]
     outs = [torch.zeros(count, device="cuda") for _ in range(n)]
     torch.cuda.synchronize()
+    handles = [comms[r].register(outs[r].data_ptr(), a.bytes) for r in range(n)] if a.register else []
 
     def step():
         ra.group_start()
@@ -61,8 +63,12 @@ def main():
     for r in range(1, n):
         want += ins[r]
     ok = all(torch.equal(o, want) for o in outs) and all(c.async_error() == 0 for c in comms)
-    hbm = (2 + 4 * (n - 1) / n) * a.bytes * n           # bytes all ranks move through HBM per all-reduce
-    print(json.dumps({"ranks_on_one_gpu": n, "bytes": a.bytes, "ms_per_allreduce": round(ms, 4), "exact": ok,
+    # bytes all ranks move through HBM per all-reduce: input read and output written once, every scattered piece
+    # written to a window and read back; the same again for the gathered pieces unless they are written directly
+    hbm = (2 + (2 if a.register else 4) * (n - 1) / n) * a.bytes * n
+    for r, h in enumerate(handles):
+        comms[r].deregister(h)
+    print(json.dumps({"ranks_on_one_gpu": n, "registered": bool(handles), "gather_phase_pieces": comms[0].stats(), "bytes": a.bytes, "ms_per_allreduce": round(ms, 4), "exact": ok,
                       "plan": comms[0].plan_info(0, count, ra.ncclFloat32),
                       "hbm_bytes_all_ranks": hbm, "hbm_GBps": round(hbm / ms / 1e6, 1)}))
     for c in comms:
