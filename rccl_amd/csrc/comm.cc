@@ -56,6 +56,14 @@ void readTunables(ncclComm* c) {
   if (ch < mn) ch = mn;
   if (ch < 1) ch = 1;
   if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
+  // Every workgroup of a launch waits for workgroups on other GPUs, so all of them must be resident at once:
+  // one 1024-thread workgroup per compute unit, three roles per channel in the all-reduce.
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= 3 && ch > cus / 3) {
+    RA_INFO("device %d has %d compute units: %ld channels reduced to %d", c->device, cus, ch, cus / 3);
+    ch = cus / 3;
+  }
+  (void)hipGetLastError();
   c->maxChannels = (int)ch;
   long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 1024));
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;

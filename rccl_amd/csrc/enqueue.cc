@@ -189,8 +189,15 @@ ncclResult_t launchOne(const RaCollArgs& a) {
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
-  hipError_t e = p.proto == 1 ? raLaunchLL(c->devComm, w, a.dtype, devOp, a.stream)
-                              : raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);
+  hipError_t e;
+  if (p.proto == 1 && a.coll == RA_COLL_ALLGATHER) {
+    w.count = a.count * es;                                // bytes: the copy is the same for every element type
+    e = raLaunchLL(c->devComm, w, ncclInt8, RA_OP_SUM, a.stream);
+  } else if (p.proto == 1) {
+    e = raLaunchLL(c->devComm, w, a.dtype, devOp, a.stream);
+  } else {
+    e = raLaunchColl(c->devComm, w, a.dtype, devOp, p.grid, p.block, a.stream);
+  }
   if (e != hipSuccess) { RA_WARN("collective kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
   return ncclSuccess;
 }
@@ -265,7 +272,11 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   p->grid = gridFor(coll, algo, p->nChannels);
   // Small all-reduces on the all-pairs schedule take the one-shot low-latency protocol
   // (the reference switches to LL below 256-512 KiB, src/graph/tuning.cc:632-671).
-  if (allowLL && coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && n > 1 && count * es <= RA_LL_MAX_BYTES) {
+  // Reduce-scatter and all-gather take it up to the same payload per rank: like the all-reduce they need every
+  // peer's lines to finish, which is the flow control of the two alternating line buffers (broadcast and reduce
+  // do not have that property and stay on the FIFO).
+  const bool llColl = coll == RA_COLL_ALLREDUCE || coll == RA_COLL_REDUCESCATTER || coll == RA_COLL_ALLGATHER;
+  if (allowLL && llColl && algo == RA_ALGO_DIRECT && n > 1 && count * es <= RA_LL_MAX_BYTES) {
     p->proto = 1;
     p->nChannels = RA_LL_GRID;
     p->grid = RA_LL_GRID;

@@ -1188,6 +1188,33 @@ __device__ __forceinline__ u32x4 llLoadLine(const char* p) {
   return v;
 }
 
+// Waits until the 16-byte line at lp carries `epoch` in both flag words; false once the communicator gave up.
+__device__ __forceinline__ bool llWaitLine(const RaDevComm* comm, const char* lp, uint32_t epoch, bool& dead, u32x4& line) {
+  line = llLoadLine(lp);
+  if (!dead && (line.y != epoch || line.w != epoch)) {
+    const uint64_t t0 = wall_clock64();
+    uint32_t spins = 0;
+    do {
+      __builtin_amdgcn_s_sleep(1);
+      line = llLoadLine(lp);
+      if ((++spins & 0xff) == 0) {
+        const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        if (asked || wall_clock64() - t0 > comm->timeoutTicks) {
+          uint32_t expect = RA_ERR_NONE;
+          __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
+                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          dead = true;
+          break;
+        }
+      }
+    } while (line.y != epoch || line.w != epoch);
+  }
+  return !dead;
+}
+
+// All-reduce, reduce-scatter (rank p is sent block p) and all-gather (no fold: every sender's lines are copied
+// to its block of recvbuff; launched with T = int8 and a byte count).  All three need every peer's lines to
+// finish, which is what keeps any rank from running two launches ahead of another.
 template <typename T, int OP>
 __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDevComm* __restrict__ comm, RaWork w) {
   const int n = comm->nRanks, r = comm->rank;
@@ -1196,52 +1223,45 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   const int buf = (int)(epoch & 1u);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
+  const bool scatter = w.coll == RA_COLL_REDUCESCATTER, gather = w.coll == RA_COLL_ALLGATHER;
   const size_t nUnits = (w.count * sizeof(T) + 7) / 8;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
   // 1. my contribution to everyone
   for (size_t u = gtid; u < nUnits; u += gsize) {
-    uint64_t v = llLoadUnit<T>(in, u, w.count);
-    if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
-    u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
+    uint64_t v = 0;
+    if (!scatter) {
+      v = llLoadUnit<T>(in, u, w.count);
+      if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
+    }
     for (int i = 1; i < n; i++) {
       const int p = (r + i) % n;
+      if (scatter) {
+        v = llLoadUnit<T>(in + (size_t)p * w.count, u, w.count);
+        if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
+      }
+      u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
       stSys((u32x4*)(comm->win[p] + raLLOffset(comm->lay, buf, r)) + u, line);
     }
   }
-  // 2. fold what arrives, in rank order
+  // 2. fold (or place) what arrives, in rank order
   bool dead = false;
+  const T* mine = scatter ? in + (size_t)r * w.count : in;
   for (size_t u = gtid; u < nUnits; u += gsize) {
     uint64_t acc = 0;
     for (int q = 0; q < n; q++) {
       uint64_t x;
       if (q == r) {
-        x = llLoadUnit<T>(in, u, w.count);
+        x = llLoadUnit<T>(mine, u, w.count);
         if (OP == RA_OP_PREMULSUM) x = llScale<T, true>(x, w.opArg);
       } else {
-        const char* lp = comm->win[r] + raLLOffset(comm->lay, buf, q) + u * 16;
-        u32x4 line = llLoadLine(lp);
-        if (!dead && (line.y != epoch || line.w != epoch)) {
-          const uint64_t t0 = wall_clock64();
-          uint32_t spins = 0;
-          do {
-            __builtin_amdgcn_s_sleep(1);
-            line = llLoadLine(lp);
-            if ((++spins & 0xff) == 0) {
-              const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-              if (asked || wall_clock64() - t0 > comm->timeoutTicks) {
-                uint32_t expect = RA_ERR_NONE;
-                __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
-                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                dead = true;
-                break;
-              }
-            }
-          } while (line.y != epoch || line.w != epoch);
-        }
+        u32x4 line;
+        llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, q) + u * 16, epoch, dead, line);
         x = (uint64_t)line.x | ((uint64_t)line.z << 32);
       }
-      acc = q == 0 ? x : llRed<T, OP>(acc, x);
+      if (gather) { if (!dead) llStoreUnit<T>(out + (size_t)q * w.count, u, w.count, x); }
+      else acc = q == 0 ? x : llRed<T, OP>(acc, x);
     }
+    if (gather) continue;
     if (OP == RA_OP_SUMPOSTDIV) acc = llScale<T, false>(acc, w.opArg);
     if (!dead) llStoreUnit<T>(out, u, w.count, acc);
   }

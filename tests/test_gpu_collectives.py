@@ -195,6 +195,22 @@ def test_low_latency_protocol(bed):
                               (orc.BF16, orc.AVG, 65536 + 3), (orc.I64, orc.AVG, 1023), (orc.F64, orc.SUM, 32768), (orc.F32, orc.SUM, 65536)):
             _check_allreduce(bed, dt, op, count)
         _check_allreduce(bed, orc.I32, orc.PROD, 384, in_place=True)
+        # reduce-scatter and all-gather take the same protocol up to 256 KiB per rank (unaligned blocks included)
+        assert bed.plan(COLL_REDUCESCATTER, 1000, orc.F32)["proto"] == want_proto
+        assert bed.plan(COLL_ALLGATHER, 1000, orc.F32)["proto"] == want_proto
+        assert bed.plan(COLL_ALLGATHER, 65537, orc.F32)["proto"] == 0
+        for dt, op, count, in_place in ((orc.F32, orc.SUM, 1000, False), (orc.I32, orc.PROD, 5423, True), (orc.U8, orc.MIN, 246, True),
+                                        (orc.BF16, orc.AVG, 10481, False), (orc.F64, orc.MAX, 32768, False), (orc.I64, orc.AVG, 1023, False)):
+            ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
+            outs = bed.run(COLL_REDUCESCATTER, dt, op, count, ins, count * _es(dt), in_place=in_place, iters=1)
+            plan = bed.plan(COLL_REDUCESCATTER, count, dt)
+            for r in range(n):
+                assert ex.check(dt, outs[r], ex.reduce_scatter(dt, op, ins, r, plan), exact=True) is None, (dt, op, count, r)
+        for dt, count, in_place in ((orc.F16, 1001, False), (orc.I32, 264, True), (orc.I8, 958, True), (orc.F64, 586, False), (orc.U8, 2500, False)):
+            ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+            outs = bed.run(COLL_ALLGATHER, dt, orc.SUM, count, ins, count * n * _es(dt), in_place=in_place, iters=1 if in_place else 3)
+            for o in outs:
+                assert ex.check(dt, o, orc.all_gather_expected(ins), exact=True) is None, (dt, count)
     bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
 
 
