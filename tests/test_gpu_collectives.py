@@ -164,6 +164,33 @@ def test_broadcast_and_reduce(bed):
                     assert (outs[r] == 0xA5).all()
 
 
+def test_unaligned_user_pointers_and_guards(bed):
+    """sendbuff / recvbuff aligned to the element only (not to 16 bytes), every collective and schedule; the test bed
+    also checks that no byte outside recvbuff changes (tools/fuzz_collectives.py is the long, randomised version)."""
+    n = bed.nranks
+    for algo in ("Direct", "Ring"):
+        bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": "Simple"})
+        for dt, op, count, pad, in_place in ((orc.F32, orc.SUM, 70001, (4, 12), False), (orc.BF16, orc.AVG, 33333, (2, 6), False),
+                                             (orc.I8, orc.MAX, 100003, (1, 3), True), (orc.F64, orc.PROD, 9001, (8, 8), True)):
+            e = _es(dt)
+            ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
+            outs = bed.run(COLL_ALLREDUCE, dt, op, count, ins, count * e, in_place=in_place, pad=pad)
+            want = ex.allreduce(dt, op, ins, bed.plan(COLL_ALLREDUCE, count, dt))
+            for r in range(n):
+                assert ex.check(dt, outs[r], want, exact=True) is None, (algo, orc.DT_NAMES[dt], r)
+            c2 = count // n
+            ins = [orc.fill_pattern(dt, c2 * n, r) for r in range(n)]
+            outs = bed.run(COLL_REDUCESCATTER, dt, op, c2, ins, c2 * e, in_place=in_place, pad=pad)
+            plan = bed.plan(COLL_REDUCESCATTER, c2, dt)
+            for r in range(n):
+                assert ex.check(dt, outs[r], ex.reduce_scatter(dt, op, ins, r, plan), exact=True) is None, (algo, orc.DT_NAMES[dt], r)
+            ins = [orc.fill_pattern(dt, c2, r) for r in range(n)]
+            outs = bed.run(COLL_ALLGATHER, dt, orc.SUM, c2, ins, c2 * n * e, in_place=in_place, pad=pad)
+            for o in outs:
+                assert ex.check(dt, o, orc.all_gather_expected(ins), exact=True) is None, (algo, orc.DT_NAMES[dt])
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
+
+
 def test_back_to_back_and_reinit(bed):
     """Step counters persist across launches; communicators can be destroyed and recreated."""
     bed.init_comms({"NCCL_ALGO": None})

@@ -74,25 +74,33 @@ def _child(rank, nranks, device, conn, env):
                         print(f"testbed rank {rank}: an uploaded buffer read back differently (attempt {attempt})", flush=True)
                     raise RuntimeError("test bed: a host-to-device upload does not read back as written")
 
+                # pad = (bytes in front of sendbuff, bytes in front of recvbuff): unaligned user pointers.  Every
+                # buffer ends in a 64-byte guard that must come back untouched.
+                pad_s, pad_r = a.get("pad") or (0, 0)
+                GUARD = 64
                 if a["in_place"]:
                     # buffer sized for the larger side; input placed where the API expects it
                     nbytes = max(host_in.size, a["out_bytes"])
-                    image = np.zeros(nbytes, dtype=np.uint8)
+                    image = np.full(pad_r + nbytes + GUARD, 0xA5, dtype=np.uint8)
+                    image[pad_r:pad_r + nbytes] = 0
                     off = rank * a["count"] * es if a["coll"] == COLL_ALLGATHER else 0
-                    image[off:off + host_in.size] = host_in
+                    image[pad_r + off:pad_r + off + host_in.size] = host_in
                     buf = upload(image)
+                    base = buf.data_ptr() + pad_r
                     if a["coll"] == COLL_ALLGATHER:
-                        send_ptr, recv_ptr = buf.data_ptr() + off, buf.data_ptr()
+                        send_ptr, recv_ptr = base + off, base
                     elif a["coll"] == COLL_REDUCESCATTER:
-                        send_ptr, recv_ptr = buf.data_ptr(), buf.data_ptr() + rank * a["count"] * es
+                        send_ptr, recv_ptr = base, base + rank * a["count"] * es
                     else:
-                        send_ptr = recv_ptr = buf.data_ptr()
+                        send_ptr = recv_ptr = base
                     out_view = lambda: buf
+                    guards = [(0, pad_r), (pad_r + nbytes, pad_r + nbytes + GUARD)]
                 else:
-                    inp = upload(host_in.copy())
-                    out = upload(np.full(a["out_bytes"], 0xA5, dtype=np.uint8))
-                    send_ptr, recv_ptr = inp.data_ptr(), out.data_ptr()
+                    inp = upload(np.concatenate([np.zeros(pad_s, dtype=np.uint8), host_in]))
+                    out = upload(np.full(pad_r + a["out_bytes"] + GUARD, 0xA5, dtype=np.uint8))
+                    send_ptr, recv_ptr = inp.data_ptr() + pad_s, out.data_ptr() + pad_r
                     out_view = lambda: out
+                    guards = [(0, pad_r), (pad_r + a["out_bytes"], pad_r + a["out_bytes"] + GUARD)]
                 op = a["op"]
                 user_op = None
                 if a.get("premul") is not None:
@@ -121,7 +129,7 @@ def _child(rank, nranks, device, conn, env):
                         issue()
                     g.replay()
                     stream.synchronize()
-                    out_view().fill_(0x3C)
+                    out_view()[pad_r:pad_r + a["out_bytes"]].fill_(0x3C)
                     torch.cuda.synchronize()
                     g.replay()
                 with torch.cuda.stream(stream):
@@ -134,12 +142,18 @@ def _child(rank, nranks, device, conn, env):
                     comm.destroy_op(user_op)
                 err = comm.async_error()
                 res = out_view().cpu().numpy()
+                for lo, hi in guards:
+                    if not np.all(res[lo:hi] == 0xA5):
+                        raise RuntimeError(f"rank {rank}: bytes outside the receive buffer were written (guard {lo}:{hi})")
+                res = res[pad_r:]
                 if a["in_place"]:
                     if a["coll"] == COLL_REDUCESCATTER:
                         off = rank * a["count"] * es
                         res = res[off:off + a["out_bytes"]]
                     else:
                         res = res[:a["out_bytes"]]
+                else:
+                    res = res[:a["out_bytes"]]
                 conn.send(("ok", (err, res.tobytes())))
             elif cmd == "reg_prepare":
                 # args: dict(dtype, count, input(bytes), in_place, register_recv): buffers that stay alive across commands
@@ -234,13 +248,13 @@ class TestBed:
         return info
 
     def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False,
-            skip_ranks=(), expect_errors=False, root=0):
+            skip_ranks=(), expect_errors=False, root=0, pad=None):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                      out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
-                     graph=graph, skip=r in skip_ranks, root=root)
+                     graph=graph, skip=r in skip_ranks, root=root, pad=pad)
                 for r in range(self.nranks)]
         res = self._all("coll", args)
         if expect_errors:
