@@ -45,10 +45,11 @@ struct DeviceGuard {
 void readTunables(ncclComm* c) {
   // NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS as in src/graph/connect.cc:521-545; the native
   // knob is RCCL_AMD_NCHANNELS.
-  // Default: 8 channels per xGMI link in use, between 16 and 56 (56 = 8 x 7 links at 8 ranks; the
-  // reference also ends up with 56 channels on an 8-GPU all-to-all node, src/graph/connect.cc:638-660).
+  // Default: 8 channels per xGMI link in use, between 32 and 56 (56 = 8 x 7 links at 8 ranks; the
+  // reference also ends up with 56 channels on an 8-GPU all-to-all node, src/graph/connect.cc:638-660, and
+  // recommends 32 channels for 2 and 24 for 4 MI300X, README.md:194-203).
   long dflt = 8L * (c->nRanks - 1);
-  if (dflt < 16) dflt = 16;
+  if (dflt < 32) dflt = 32;
   if (dflt > 56) dflt = 56;
   long ch = envLong("RCCL_AMD_NCHANNELS", -1);
   if (ch < 0) ch = envLong("NCCL_MAX_NCHANNELS", dflt);
