@@ -164,6 +164,35 @@ def test_broadcast_and_reduce(bed):
                     assert (outs[r] == 0xA5).all()
 
 
+def test_managed_memory_buffers(bed):
+    """hipMallocManaged send/receive buffers, the reference's managed-memory cases (AllReduceTests.cpp:86-103 uint8/uint64
+    sum N=2500; ReduceScatterTests.cpp int64/uint8 avg N=1024; AllGatherTests.cpp uint8 N in {1039203, 2500})."""
+    bed.init_comms({"NCCL_ALGO": None})
+    n = bed.nranks
+    for dt in (orc.U8, orc.U64):
+        ins = [orc.fill_pattern(dt, 2500, r) for r in range(n)]
+        outs = bed.run(COLL_ALLREDUCE, dt, orc.SUM, 2500, ins, 2500 * _es(dt), managed=True)
+        for o in outs:
+            assert ex.check(dt, o, orc.host_fold(dt, orc.SUM, ins), exact=True) is None
+    for dt in (orc.I64, orc.U8):
+        ins = [orc.fill_pattern(dt, 1024 * n, r) for r in range(n)]
+        outs = bed.run(COLL_REDUCESCATTER, dt, orc.AVG, 1024, ins, 1024 * _es(dt), managed=True)
+        for r in range(n):
+            assert ex.check(dt, outs[r], orc.reduce_scatter_expected(dt, orc.AVG, ins, r), exact=True) is None
+    for count in (1039203 // 4, 2500):                      # (the large case trimmed to a quarter)
+        ins = [orc.fill_pattern(orc.U8, count, r) for r in range(n)]
+        outs = bed.run(COLL_ALLGATHER, orc.U8, orc.SUM, count, ins, count * n, managed=True)
+        for o in outs:
+            assert ex.check(orc.U8, o, orc.all_gather_expected(ins), exact=True) is None
+    # a large managed all-reduce through the FIFO protocol
+    count = (1 << 20) + 5
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    outs = bed.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4, managed=True)
+    want = ex.allreduce(orc.F32, orc.SUM, ins, bed.plan(COLL_ALLREDUCE, count, orc.F32))
+    for o in outs:
+        assert ex.check(orc.F32, o, want, exact=True) is None
+
+
 def test_unaligned_user_pointers_and_guards(bed):
     """sendbuff / recvbuff aligned to the element only (not to 16 bytes), every collective and schedule; the test bed
     also checks that no byte outside recvbuff changes (tools/fuzz_collectives.py is the long, randomised version)."""

@@ -78,6 +78,36 @@ def _child(rank, nranks, device, conn, env):
                 # buffer ends in a 64-byte guard that must come back untouched.
                 pad_s, pad_r = a.get("pad") or (0, 0)
                 GUARD = 64
+                managed = []
+                if a.get("managed"):
+                    # hipMallocManaged buffers (the reference's managed-memory test mode, TestBedChild.cpp ALLOCATE_MEM):
+                    # filled and read back through the host mapping, no torch tensor involved.
+                    import ctypes
+                    hip = ctypes.CDLL("libamdhip64.so")
+
+                    class Managed:
+                        def __init__(self, image):
+                            self.n = image.size
+                            p = ctypes.c_void_p()
+                            rc = hip.hipMallocManaged(ctypes.byref(p), ctypes.c_size_t(max(self.n, 1)), ctypes.c_uint(1))
+                            if rc != 0:
+                                raise RuntimeError(f"hipMallocManaged failed with {rc}")
+                            self.p = p.value
+                            ctypes.memmove(self.p, image.ctypes.data, self.n)
+                            managed.append(self)
+
+                        def data_ptr(self):
+                            return self.p
+
+                        def cpu(self):
+                            out = np.empty(self.n, dtype=np.uint8)
+                            ctypes.memmove(out.ctypes.data, self.p, self.n)
+                            return torch.from_numpy(out)
+
+                        def free(self):
+                            hip.hipFree(ctypes.c_void_p(self.p))
+
+                    upload = Managed
                 if a["in_place"]:
                     # buffer sized for the larger side; input placed where the API expects it
                     nbytes = max(host_in.size, a["out_bytes"])
@@ -141,7 +171,10 @@ def _child(rank, nranks, device, conn, env):
                 if user_op is not None:
                     comm.destroy_op(user_op)
                 err = comm.async_error()
+                torch.cuda.synchronize()
                 res = out_view().cpu().numpy()
+                for m in managed:
+                    m.free()
                 for lo, hi in guards:
                     if not np.all(res[lo:hi] == 0xA5):
                         raise RuntimeError(f"rank {rank}: bytes outside the receive buffer were written (guard {lo}:{hi})")
@@ -248,13 +281,13 @@ class TestBed:
         return info
 
     def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False,
-            skip_ranks=(), expect_errors=False, root=0, pad=None):
+            skip_ranks=(), expect_errors=False, root=0, pad=None, managed=False):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                      out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
-                     graph=graph, skip=r in skip_ranks, root=root, pad=pad)
+                     graph=graph, skip=r in skip_ranks, root=root, pad=pad, managed=managed)
                 for r in range(self.nranks)]
         res = self._all("coll", args)
         if expect_errors:
