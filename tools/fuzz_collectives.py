@@ -52,7 +52,8 @@ def main():
             if done >= args.cases:
                 break
             done += 1
-            coll = [COLL_ALLREDUCE, COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE][int(rng.integers(0, 6))]
+            # broadcast / reduce are one-hop schedules for up to 8 ranks
+            coll = [COLL_ALLREDUCE, COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE][int(rng.integers(0, 6 if n <= 8 else 4))]
             dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
             op = OPS[int(rng.integers(0, len(OPS)))]
             e = es(dt)
