@@ -157,7 +157,10 @@ def main():
             heads = [head]
         want = orc.host_fold(orc.F32, orc.SUM, heads)
         got = recvbuf[:65536].float().cpu().numpy()
-        verified = bool(np.array_equal(got, want))
+        # the all-pairs schedule folds in rank order like the host fold: same bits; ring and chain orders differ
+        # in the last place, so they are held to the reference's fp32 tolerance instead
+        direct = n == 1 or comm.plan_info(0, count, dt_code)["algo"] == 0
+        verified = bool(np.array_equal(got, want)) if direct else bool(orc.first_mismatch(orc.F32, got, want) < 0)
 
     per_step = wall / args.steps
     if args.coll == "allreduce":
