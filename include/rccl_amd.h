@@ -187,6 +187,11 @@ ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataTy
  * straight into a peer's registered receive buffer, and pieces sent through the FIFO.  Synchronous. */
 ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces);
 
+/* Measurement aid (RCCL_AMD_TUNE_FLAGS=32): 100 MHz ticks thread 0 of every collective workgroup spent, summed over
+ * workgroups and launches, per role (3 roles x {waiting for peers, reduce-copy body, draining memory operations,
+ * fence and posting, number of steps}); ticks must hold 15 values. */
+ncclResult_t rcclAmdCommStepTimers(ncclComm_t comm, uint64_t* ticks);
+
 /* Rendezvous check without a GPU: joins the endpoint named by `id` as `rank` of `nranks`, all-gathers
  * `bytes` bytes per rank into `all`, and leaves.  It is the exchange ncclCommInitRank performs for the
  * window handles (role of bootstrapAllGather, src/bootstrap.cc), callable from CPU-only tests. */

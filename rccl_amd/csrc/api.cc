@@ -134,6 +134,21 @@ RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, ui
   return ncclSuccess;
 }
 
+RA_API ncclResult_t rcclAmdCommStepTimers(ncclComm_t comm, uint64_t* ticks) {
+  RA_CHECK(raCommCheck(comm, "rcclAmdCommStepTimers"));
+  if (!ticks) return ncclInvalidArgument;
+  memset(ticks, 0, 15 * sizeof(uint64_t));
+  if (comm->stats) {
+    int old = 0;
+    (void)hipGetDevice(&old);
+    (void)hipSetDevice(comm->device);
+    hipError_t e = hipMemcpy(ticks, comm->stats + 8, 15 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipSetDevice(old);
+    if (e != hipSuccess) return ncclUnhandledCudaError;
+  }
+  return ncclSuccess;
+}
+
 RA_API ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype,
                                              ncclScalarResidence_t residence, ncclComm_t comm) {
   // src/enqueue.cc:2219-2270

@@ -448,9 +448,35 @@ static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int t
   }
 }
 
-// Up to RA_MAX_SRCS independent copies src[j] -> dst[j] of `nbytes` each in ONE pass: every thread
-// has one 16-byte load per pair in flight, so the n-1 pieces a scatter or gather role moves per
-// round share a single load-latency ramp instead of paying it once per piece.
+// Up to RA_MAX_SRCS independent copies src[j] -> dst[j] of `nbytes` each in ONE pass: every thread keeps
+// pairs x rows = up to 8 16-byte loads in flight (ROWS consecutive 16 KiB rows of every pair per iteration), so
+// the n-1 pieces a scatter or gather role moves per round share a single load-latency ramp instead of paying
+// it once per piece, and a single pair (2 ranks) still has eight loads in flight per thread.
+template <int ROWS>
+__device__ __forceinline__ size_t pairRows(const uint64_t* s, const uint64_t* d, int np, uint32_t sysMask, size_t nbytes,
+                                           uint32_t lane16, size_t row) {
+  constexpr int NP = RA_MAX_SRCS / ROWS;            // pairs this instantiation can hold
+  const size_t span = row * ROWS;
+  const size_t full = nbytes / span * span;
+  for (size_t b = 0; b < full; b += span) {
+    u32x4 v[NP][ROWS];
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+#pragma unroll
+      for (int r = 0; r < ROWS; r++)
+        if (j < np) v[j][r] = ldAt(s[j] + b + (size_t)r * row, lane16);
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+#pragma unroll
+      for (int r = 0; r < ROWS; r++)
+        if (j < np) {
+          if (sysMask >> j & 1) stSysAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
+          else stAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
+        }
+  }
+  return full;
+}
+
 static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn, int tid, int nthr) {
   const int np = __builtin_amdgcn_readfirstlane(a.ns);
   const size_t nbytes = uniform64(nbytesIn);
@@ -470,20 +496,12 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
       s[j] = uniform64((uint64_t)a.src[j < np ? j : 0]);
       d[j] = uniform64((uint64_t)a.dst[j < np ? j : 0]);
     }
-    const size_t full = nbytes / row * row;
-    for (size_t b = 0; b < full; b += row) {
-      u32x4 v[RA_MAX_SRCS];
-#pragma unroll
-      for (int j = 0; j < RA_MAX_SRCS; j++)
-        if (j < np) v[j] = ldAt(s[j] + b, lane16);
-#pragma unroll
-      for (int j = 0; j < RA_MAX_SRCS; j++)
-        if (j < np) {
-          if (sysMask >> j & 1) stSysAt(d[j] + b, lane16, v[j]);
-          else stAt(d[j] + b, lane16, v[j]);
-        }
-    }
-    done = full;
+    if (np == 1) done = pairRows<8>(s, d, np, sysMask, nbytes, lane16, row);
+    else if (np == 2) done = pairRows<4>(s, d, np, sysMask, nbytes, lane16, row);
+    else if (np <= 4) done = pairRows<2>(s, d, np, sysMask, nbytes, lane16, row);
+    // the rest (and everything for 5 to 8 pairs) one row of every pair at a time
+    for (int j = 0; j < RA_MAX_SRCS; j++) { s[j] += done; d[j] += done; }
+    done += pairRows<1>(s, d, np, sysMask, nbytes - done, lane16, row);
   }
   // what is left (ragged end, or everything when a pointer is unaligned): pair by pair, bytes
   if (done < nbytes) {
@@ -533,6 +551,7 @@ struct Ctx {
   int ch, tid, nthr, rank, nRanks;
   uint32_t stepBytes;
   int auxRecv = 0, auxSend = 0;   // this step carries the once-per-launch words (first step of a workgroup only)
+  uint64_t tk[5] = {0, 0, 0, 0, 0};   // tuneFlags 32: ticks thread 0 spent waiting / in the body / draining / posting, steps
 
   __device__ __forceinline__ uint64_t* flag(int owner, int which, int peer, int kind) const {
     return (uint64_t*)(comm->win[owner] + raFlagOffset(comm->lay, which, ch, peer, kind));
@@ -565,7 +584,10 @@ struct Ctx {
     __syncthreads();
   }
   // Persist the step counters this workgroup advanced.
-  __device__ void finish() {
+  __device__ void finish(int role = 0) {
+    if ((comm->tuneFlags & 32) && tid == 0 && role < 3)
+      for (int k = 0; k < 5; k++)
+        __hip_atomic_fetch_add(&comm->stats[8 + role * 5 + k], tk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int n = nRanks * RA_NKINDS;
     if (tid < n) {
@@ -602,6 +624,9 @@ struct Ctx {
   // fills sendSlot()s.  Returns false once the communicator was aborted.
   template <class F>
   __device__ __forceinline__ bool step(uint32_t recvMask, int rk, uint32_t sendMask, int sk, F&& body) {
+    const bool timed = (comm->tuneFlags & 32) && tid == 0;
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (timed) t0 = wall_clock64();
     if (tid < RA_MAX_RANKS) {
       if (recvMask >> tid & 1) {
         spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
@@ -617,10 +642,13 @@ struct Ctx {
     }
     if (tid < 64) drainVmem();
     __syncthreads();
+    if (timed) t1 = wall_clock64();
     const bool ok = !sh->aborted;
     if (ok) body();
+    if (timed) t2 = wall_clock64();
     drainVmem();       // every wave: its loads have returned and its stores are acknowledged
     __syncthreads();
+    if (timed) t3 = wall_clock64();
     if (tid < 64) {
       // Release before the flag.  Window data is written with system-scope write-through stores and every
       // wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of the flag
@@ -655,6 +683,11 @@ struct Ctx {
         }
       }
       if (tid == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
+    }
+    if (timed) {
+      drainVmem();
+      const uint64_t t4 = wall_clock64();
+      tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[3] += t4 - t3; tk[4] += 1;
     }
     __syncthreads();
     return ok;
@@ -1288,6 +1321,6 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   } else {
     if (w.coll == RA_COLL_ALLREDUCE) chainAllReduce<T, OP>(cx, w, role);
   }
-  cx.finish();
+  cx.finish(role);
 }
 

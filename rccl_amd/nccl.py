@@ -30,7 +30,7 @@ EXPORTS = [
     "ncclGetVersion", "ncclGetErrorString", "ncclGetLastError", "ncclCommGetAsyncError", "ncclGetUniqueId",
     "ncclCommInitRankConfig", "ncclCommInitRank", "ncclCommInitAll", "ncclCommFinalize", "ncclCommDestroy",
     "ncclCommAbort", "ncclCommCount", "ncclCommCuDevice", "ncclCommUserRank", "ncclMemAlloc", "ncclMemFree",
-    "ncclCommRegister", "ncclCommDeregister", "rcclAmdCommStats",
+    "ncclCommRegister", "ncclCommDeregister", "rcclAmdCommStats", "rcclAmdCommStepTimers",
     "ncclRedOpCreatePreMulSum", "ncclRedOpDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather",
     "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
     "ncclCommSplit", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
@@ -85,6 +85,7 @@ def lib():
         L.ncclMemFree.argtypes = [vp]
         L.ncclCommRegister.argtypes = [vp, vp, sz, ctypes.POINTER(vp)]
         L.ncclCommDeregister.argtypes = [vp, vp]
+        L.rcclAmdCommStepTimers.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
         L.rcclAmdCommStats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.ncclRedOpCreatePreMulSum.argtypes = [ctypes.POINTER(ci), vp, ci, ci, vp]
         L.ncclRedOpDestroy.argtypes = [ci, vp]
@@ -255,6 +256,18 @@ class Communicator:
         d, f = ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().rcclAmdCommStats(self.handle, ctypes.byref(d), ctypes.byref(f)), "rcclAmdCommStats")
         return {"direct_pieces": d.value, "fifo_pieces": f.value}
+
+    def step_timers(self):
+        """With RCCL_AMD_TUNE_FLAGS=32: microseconds per step and role spent waiting / in the body / draining / posting."""
+        t = (ctypes.c_uint64 * 15)()
+        _check(lib().rcclAmdCommStepTimers(self.handle, t), "rcclAmdCommStepTimers")
+        out = {}
+        for role, name in enumerate(("role0", "role1", "role2")):
+            steps = t[role * 5 + 4]
+            if steps:
+                out[name] = {k: round(t[role * 5 + i] / steps / 100.0, 2) for i, k in enumerate(("wait_us", "body_us", "drain_us", "post_us"))}
+                out[name]["steps"] = steps
+        return out
 
     def finalize(self):
         _check(lib().ncclCommFinalize(self.handle), "ncclCommFinalize")

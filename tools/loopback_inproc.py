@@ -68,7 +68,7 @@ def main():
     hbm = (2 + (2 if a.register else 4) * (n - 1) / n) * a.bytes * n
     for r, h in enumerate(handles):
         comms[r].deregister(h)
-    print(json.dumps({"ranks_on_one_gpu": n, "registered": bool(handles), "gather_phase_pieces": comms[0].stats(), "bytes": a.bytes, "ms_per_allreduce": round(ms, 4), "exact": ok,
+    print(json.dumps({"ranks_on_one_gpu": n, "registered": bool(handles), "gather_phase_pieces": comms[0].stats(), "step_timers": comms[0].step_timers(), "bytes": a.bytes, "ms_per_allreduce": round(ms, 4), "exact": ok,
                       "plan": comms[0].plan_info(0, count, ra.ncclFloat32),
                       "hbm_bytes_all_ranks": hbm, "hbm_GBps": round(hbm / ms / 1e6, 1)}))
     for c in comms:
