@@ -147,6 +147,42 @@ ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int
 ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm,
                            ncclConfig_t* config);                                        /* nccl.h.in:247 */
 
+
+/* ---- profiling aliases ---------------------------------------------------------------------- */
+/* The reference exports every public entry point a second time with a "p" prefix (src/include/core.h:18-27,
+ * the pncclX declarations in nccl.h.in) so that an interposer can define ncclX and call through.  Same here. */
+ncclResult_t pncclGetVersion(int* version);
+const char* pncclGetErrorString(ncclResult_t result);
+const char* pncclGetLastError(ncclComm_t comm);
+ncclResult_t pncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError);
+ncclResult_t pncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t pncclCommInitRankConfig(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank, ncclConfig_t* config);
+ncclResult_t pncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t pncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist);
+ncclResult_t pncclCommFinalize(ncclComm_t comm);
+ncclResult_t pncclCommDestroy(ncclComm_t comm);
+ncclResult_t pncclCommAbort(ncclComm_t comm);
+ncclResult_t pncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t pncclCommCuDevice(const ncclComm_t comm, int* device);
+ncclResult_t pncclCommUserRank(const ncclComm_t comm, int* rank);
+ncclResult_t pncclMemAlloc(void** ptr, size_t size);
+ncclResult_t pncclMemFree(void* ptr);
+ncclResult_t pncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle);
+ncclResult_t pncclCommDeregister(const ncclComm_t comm, void* handle);
+ncclResult_t pncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype, ncclScalarResidence_t residence, ncclComm_t comm);
+ncclResult_t pncclRedOpDestroy(ncclRedOp_t op, ncclComm_t comm);
+ncclResult_t pncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclGroupStart(void);
+ncclResult_t pncclGroupEnd(void);
+ncclResult_t pncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config);
+
 /* ---- extensions (no counterpart in nccl.h.in) -------------------------------- */
 
 /* Local N-source reduce-copy on the current device: dst[i] = src[0][i] (op) ... (op) src[nsrc-1][i],

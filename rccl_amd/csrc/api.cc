@@ -267,3 +267,38 @@ RA_API ncclResult_t rcclAmdBootstrapAllGather(const ncclUniqueId* id, int rank, 
   b.close();
   return r;
 }
+
+// "p"-prefixed twins of the public entry points (src/include/core.h:18-27): an interposer defines ncclX and
+// calls pncclX.  Plain forwarding functions (this file is also seen by the device pass, which has no definitions
+// an alias could point to).
+RA_API ncclResult_t pncclGetVersion(int* version) { return ncclGetVersion(version); }
+RA_API const char* pncclGetErrorString(ncclResult_t result) { return ncclGetErrorString(result); }
+RA_API const char* pncclGetLastError(ncclComm_t comm) { return ncclGetLastError(comm); }
+RA_API ncclResult_t pncclCommGetAsyncError(ncclComm_t comm, ncclResult_t* asyncError) { return ncclCommGetAsyncError(comm, asyncError); }
+RA_API ncclResult_t pncclGetUniqueId(ncclUniqueId* uniqueId) { return ncclGetUniqueId(uniqueId); }
+RA_API ncclResult_t pncclCommInitRankConfig(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank, ncclConfig_t* config) { return ncclCommInitRankConfig(comm, nranks, commId, rank, config); }
+RA_API ncclResult_t pncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank) { return ncclCommInitRank(comm, nranks, commId, rank); }
+RA_API ncclResult_t pncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist) { return ncclCommInitAll(comm, ndev, devlist); }
+RA_API ncclResult_t pncclCommFinalize(ncclComm_t comm) { return ncclCommFinalize(comm); }
+RA_API ncclResult_t pncclCommDestroy(ncclComm_t comm) { return ncclCommDestroy(comm); }
+RA_API ncclResult_t pncclCommAbort(ncclComm_t comm) { return ncclCommAbort(comm); }
+RA_API ncclResult_t pncclCommCount(const ncclComm_t comm, int* count) { return ncclCommCount(comm, count); }
+RA_API ncclResult_t pncclCommCuDevice(const ncclComm_t comm, int* device) { return ncclCommCuDevice(comm, device); }
+RA_API ncclResult_t pncclCommUserRank(const ncclComm_t comm, int* rank) { return ncclCommUserRank(comm, rank); }
+RA_API ncclResult_t pncclMemAlloc(void** ptr, size_t size) { return ncclMemAlloc(ptr, size); }
+RA_API ncclResult_t pncclMemFree(void* ptr) { return ncclMemFree(ptr); }
+RA_API ncclResult_t pncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle) { return ncclCommRegister(comm, buff, size, handle); }
+RA_API ncclResult_t pncclCommDeregister(const ncclComm_t comm, void* handle) { return ncclCommDeregister(comm, handle); }
+RA_API ncclResult_t pncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype, ncclScalarResidence_t residence, ncclComm_t comm) { return ncclRedOpCreatePreMulSum(op, scalar, datatype, residence, comm); }
+RA_API ncclResult_t pncclRedOpDestroy(ncclRedOp_t op, ncclComm_t comm) { return ncclRedOpDestroy(op, comm); }
+RA_API ncclResult_t pncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) { return ncclAllReduce(sendbuff, recvbuff, count, datatype, op, comm, stream); }
+RA_API ncclResult_t pncclReduceScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t comm, hipStream_t stream) { return ncclReduceScatter(sendbuff, recvbuff, recvcount, datatype, op, comm, stream); }
+RA_API ncclResult_t pncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream) { return ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); }
+RA_API ncclResult_t pncclGroupStart(void) { return ncclGroupStart(); }
+RA_API ncclResult_t pncclGroupEnd(void) { return ncclGroupEnd(); }
+RA_API ncclResult_t pncclReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root, ncclComm_t comm, hipStream_t stream) { return ncclReduce(sendbuff, recvbuff, count, datatype, op, root, comm, stream); }
+RA_API ncclResult_t pncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) { return ncclBroadcast(sendbuff, recvbuff, count, datatype, root, comm, stream); }
+RA_API ncclResult_t pncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) { return ncclBcast(buff, count, datatype, root, comm, stream); }
+RA_API ncclResult_t pncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) { return ncclSend(sendbuff, count, datatype, peer, comm, stream); }
+RA_API ncclResult_t pncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) { return ncclRecv(recvbuff, count, datatype, peer, comm, stream); }
+RA_API ncclResult_t pncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config) { return ncclCommSplit(comm, color, key, newcomm, config); }

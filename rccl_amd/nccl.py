@@ -36,6 +36,7 @@ EXPORTS = [
     "ncclCommSplit", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
     "rcclAmdPlanForConfig", "rcclAmdBootstrapAllGather",
 ]
+EXPORTS += ["p" + name for name in EXPORTS if name.startswith("nccl")]      # profiling aliases
 
 
 class ncclUniqueId(ctypes.Structure):

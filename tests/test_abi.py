@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, "include", "rccl_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:nccl|rcclAmd)[A-Za-z0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:p?nccl|rcclAmd)[A-Za-z0-9]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported():
