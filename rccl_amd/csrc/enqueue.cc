@@ -295,7 +295,12 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // peer's lines to finish, which is the flow control of the two alternating line buffers (broadcast and reduce
   // do not have that property and stay on the FIFO).
   const bool llColl = coll == RA_COLL_ALLREDUCE || coll == RA_COLL_REDUCESCATTER || coll == RA_COLL_ALLGATHER;
-  if (allowLL && llColl && algo == RA_ALGO_DIRECT && n > 1 && count * es <= RA_LL_MAX_BYTES) {
+  static const size_t llMax = []() {
+    const char* e = getenv("RCCL_AMD_LL_MAX_BYTES");
+    long v = e ? atol(e) : 0;
+    return (size_t)(v > 0 ? (v > (long)RA_LL_MAX_BYTES ? (long)RA_LL_MAX_BYTES : v) : (long)RA_LL_DEFAULT_BYTES);
+  }();
+  if (allowLL && llColl && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
     p->proto = 1;
     p->nChannels = RA_LL_GRID;
     p->grid = RA_LL_GRID;
