@@ -67,7 +67,7 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
 // store and the receiver needs no separate flag round trip.
 #define RA_LL_MAX_BYTES (1u << 20)     // payload one sender's line buffer has room for
 #define RA_LL_DEFAULT_BYTES (512u << 10)   // largest payload that takes the low-latency protocol unless RCCL_AMD_LL_MAX_BYTES says otherwise
-#define RA_LL_GRID 8                   // workgroups of every low-latency launch (fixed: each keeps its own epoch)
+#define RA_LL_GRID 16                  // workgroups of every low-latency launch (fixed: each keeps its own epoch)
 #define RA_LL_THREADS 1024
 __host__ __device__ inline size_t raLLOffset(const RaWindowLayout& l, int buf, int sender) {
   return l.llOffset + ((size_t)buf * l.nRanks + sender) * l.llBytes;
