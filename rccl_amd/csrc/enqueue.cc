@@ -295,11 +295,11 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // peer's lines to finish, which is the flow control of the two alternating line buffers (broadcast and reduce
   // do not have that property and stay on the FIFO).
   const bool llColl = coll == RA_COLL_ALLREDUCE || coll == RA_COLL_REDUCESCATTER || coll == RA_COLL_ALLGATHER;
-  static const size_t llMax = []() {
-    const char* e = getenv("RCCL_AMD_LL_MAX_BYTES");
-    long v = e ? atol(e) : 0;
-    return (size_t)(v > 0 ? (v > (long)RA_LL_MAX_BYTES ? (long)RA_LL_MAX_BYTES : v) : (long)RA_LL_DEFAULT_BYTES);
-  }();
+  // Limit: measured switch-over with ranks sharing one GPU is above 1 MiB at 2 ranks (23 us against 37 us) and about
+  // 1 MiB at 8; the one-shot exchange sends n-1 copies of the payload, so larger groups keep the smaller limit.
+  static const long llEnv = []() { const char* e = getenv("RCCL_AMD_LL_MAX_BYTES"); return e ? atol(e) : 0L; }();
+  size_t llMax = n <= 4 ? (size_t)RA_LL_MAX_BYTES : (size_t)RA_LL_DEFAULT_BYTES;
+  if (llEnv > 0) llMax = llEnv > (long)RA_LL_MAX_BYTES ? (size_t)RA_LL_MAX_BYTES : (size_t)llEnv;
   if (allowLL && llColl && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
     p->proto = 1;
     p->nChannels = RA_LL_GRID;

@@ -254,7 +254,7 @@ def test_low_latency_protocol(bed):
         # reduce-scatter and all-gather take the same protocol up to 256 KiB per rank (unaligned blocks included)
         assert bed.plan(COLL_REDUCESCATTER, 1000, orc.F32)["proto"] == want_proto
         assert bed.plan(COLL_ALLGATHER, 1000, orc.F32)["proto"] == want_proto
-        assert bed.plan(COLL_ALLGATHER, 131073, orc.F32)["proto"] == 0
+        assert bed.plan(COLL_ALLGATHER, 262145, orc.F32)["proto"] == 0
         for dt, op, count, in_place in ((orc.F32, orc.SUM, 1000, False), (orc.I32, orc.PROD, 5423, True), (orc.U8, orc.MIN, 246, True),
                                         (orc.BF16, orc.AVG, 10481, False), (orc.F64, orc.MAX, 32768, False), (orc.I64, orc.AVG, 1023, False)):
             ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
