@@ -543,6 +543,8 @@ struct ChanShared {
   uint64_t auxIn[RA_MAX_RANKS];
   uint64_t auxOut[RA_MAX_RANKS];
   uint64_t directBase[RA_MAX_RANKS];
+  // tuneFlags 32: ticks thread 0 spent waiting / in the body / draining / posting, steps; stamps of the step under way
+  uint64_t tk[5], ts[4];
 };
 
 struct Ctx {
@@ -551,7 +553,6 @@ struct Ctx {
   int ch, tid, nthr, rank, nRanks;
   uint32_t stepBytes;
   int auxRecv = 0, auxSend = 0;   // this step carries the once-per-launch words (first step of a workgroup only)
-  uint64_t tk[5] = {0, 0, 0, 0, 0};   // tuneFlags 32: ticks thread 0 spent waiting / in the body / draining / posting, steps
 
   __device__ __forceinline__ uint64_t* flag(int owner, int which, int peer, int kind) const {
     return (uint64_t*)(comm->win[owner] + raFlagOffset(comm->lay, which, ch, peer, kind));
@@ -581,13 +582,14 @@ struct Ctx {
       for (int k = 0; k < RA_NKINDS; k++) { sh->sendDirty[k] = 0; sh->recvDirty[k] = 0; }
     }
     if (tid < RA_MAX_RANKS) { sh->auxIn[tid] = 0; sh->auxOut[tid] = 0; sh->directBase[tid] = 0; }
+    if (tid < 5) sh->tk[tid] = 0;
     __syncthreads();
   }
   // Persist the step counters this workgroup advanced.
   __device__ void finish(int role = 0) {
     if ((comm->tuneFlags & 32) && tid == 0 && role < 3)
       for (int k = 0; k < 5; k++)
-        __hip_atomic_fetch_add(&comm->stats[8 + role * 5 + k], tk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&comm->stats[8 + role * 5 + k], sh->tk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int n = nRanks * RA_NKINDS;
     if (tid < n) {
@@ -625,8 +627,7 @@ struct Ctx {
   template <class F>
   __device__ __forceinline__ bool step(uint32_t recvMask, int rk, uint32_t sendMask, int sk, F&& body) {
     const bool timed = (comm->tuneFlags & 32) && tid == 0;
-    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (timed) t0 = wall_clock64();
+    if (timed) sh->ts[0] = wall_clock64();
     if (tid < RA_MAX_RANKS) {
       if (recvMask >> tid & 1) {
         spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
@@ -642,13 +643,13 @@ struct Ctx {
     }
     if (tid < 64) drainVmem();
     __syncthreads();
-    if (timed) t1 = wall_clock64();
+    if (timed) sh->ts[1] = wall_clock64();
     const bool ok = !sh->aborted;
     if (ok) body();
-    if (timed) t2 = wall_clock64();
+    if (timed) sh->ts[2] = wall_clock64();
     drainVmem();       // every wave: its loads have returned and its stores are acknowledged
     __syncthreads();
-    if (timed) t3 = wall_clock64();
+    if (timed) sh->ts[3] = wall_clock64();
     if (tid < 64) {
       // Release before the flag.  Window data is written with system-scope write-through stores and every
       // wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of the flag
@@ -687,7 +688,8 @@ struct Ctx {
     if (timed) {
       drainVmem();
       const uint64_t t4 = wall_clock64();
-      tk[0] += t1 - t0; tk[1] += t2 - t1; tk[2] += t3 - t2; tk[3] += t4 - t3; tk[4] += 1;
+      sh->tk[0] += sh->ts[1] - sh->ts[0]; sh->tk[1] += sh->ts[2] - sh->ts[1]; sh->tk[2] += sh->ts[3] - sh->ts[2];
+      sh->tk[3] += t4 - sh->ts[3]; sh->tk[4] += 1;
     }
     __syncthreads();
     return ok;

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librccl_amd.so")
+LIB_PATH = os.environ.get("RCCL_AMD_LIB") or os.path.join(_HERE, "librccl_amd.so")   # override: A/B runs of two builds
 
 # ncclResult_t (nccl.h.in:50-60)
 ncclSuccess, ncclUnhandledCudaError, ncclSystemError, ncclInternalError = 0, 1, 2, 3
