@@ -29,6 +29,32 @@ def test_allreduce_plan_geometry(n, dt, count):
     assert covered == count
 
 
+def test_plan_round_and_row_rules():
+    """Chunks are whole 1 KiB rows once they exceed the minimum; a channel gets about four rounds, eight
+    where four would need chunks above 256 KiB; small counts use only as many channels as have a full
+    minimum chunk each."""
+    f32 = ra.ncclFloat32
+    # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of ~293 KiB
+    big = ra.plan_for_config(8, 0, 1 << 28, f32, max_channels=56)
+    assert big["nChannels"] == 56 and big["grid"] == 168
+    assert big["chunkElems"] == 75008 and big["chunkElems"] * 4 % 1024 == 0
+    rounds = -(-(1 << 28) // (8 * 56 * big["chunkElems"]))
+    assert rounds == 8
+    # 1 GiB, 2 ranks, 32 channels: the slot bounds the chunk (512 KiB)
+    assert ra.plan_for_config(2, 0, 1 << 28, f32, max_channels=32)["chunkElems"] == (512 << 10) // 4
+    # 16 MiB, 2 ranks: four rounds of 64 KiB stay (eight rounds of 32 KiB were measured slower)
+    mid = ra.plan_for_config(2, 0, 1 << 22, f32, max_channels=32)
+    assert mid["nChannels"] == 32 and mid["chunkElems"] == 16384
+    # exactly 16 minimum chunks per rank pair -> 16 channels; one element more opens a 17th with a 4-element tail
+    assert ra.plan_for_config(2, 0, 1 << 18, f32, max_channels=32)["nChannels"] == 16
+    edge = ra.plan_for_config(2, 0, (1 << 18) + 1, f32, max_channels=32)
+    assert edge["nChannels"] == 17 and edge["lastChunkElems"] == 4
+    # a smaller slot bounds the chunk whatever the round rule asks for
+    assert ra.plan_for_config(8, 0, 1 << 28, f32, max_channels=56, slot_bytes=256 << 10)["chunkElems"] * 4 <= 256 << 10
+    with pytest.raises(ra.NcclError):
+        ra.plan_for_config(8, 3, 100, f32)          # broadcast/reduce have no channel plan
+
+
 def test_plan_algorithm_overrides():
     assert ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=1)["grid"] == ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=1)["nChannels"]
     t = ra.plan_for_config(8, 0, 1 << 20, ra.ncclFloat32, algo=2)
