@@ -235,6 +235,22 @@ def test_back_to_back_and_reinit(bed):
         assert np.array_equal(o.view(np.int32), want)
 
 
+def test_two_communicators_side_by_side(bed):
+    """Two communicators over the same ranks keep separate windows and step counters: launches alternating
+    between them on one stream each give the rank-order fold (small: low-latency protocol; large: FIFO)."""
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
+    n = bed.nranks
+    for count in (1250, 300001):
+        a = [orc.fill_pattern(orc.I32, count, r) for r in range(n)]
+        b = [orc.fill_pattern(orc.I32, count, 50 + r) for r in range(n)]
+        want_a, want_b = orc.host_fold(orc.I32, orc.SUM, a), orc.host_fold(orc.I32, orc.SUM, b)
+        for r, outs in enumerate(bed.run_two_comms(orc.I32, orc.SUM, count, a, b)):
+            for k, want in enumerate((want_a, want_b, want_b, want_a)):
+                assert np.array_equal(outs[k].view(np.int32), want), (count, r, k)
+    # the first communicator still works after the second is gone
+    _check_allreduce(bed, orc.F32, orc.SUM, 70001)
+
+
 def test_low_latency_protocol(bed):
     """Small all-reduces take the one-shot low-latency protocol unless NCCL_PROTO=Simple; both give the
     rank-order fold (StandaloneTests.cpp:177-187 runs its known-answer case under LL and Simple)."""
@@ -291,6 +307,11 @@ def test_hip_graph_capture_and_replay(bed):
     outs = bed.run(COLL_REDUCESCATTER, orc.F64, orc.MAX, count, ins, count * 8, graph=True)
     for r in range(n):
         assert ex.check(orc.F64, outs[r], orc.reduce_scatter_expected(orc.F64, orc.MAX, ins, r), exact=True) is None
+    count = 1001                      # small enough for the low-latency protocol: its line flags survive a replay too
+    ins = [orc.fill_pattern(orc.I32, count * n, r) for r in range(n)]
+    outs = bed.run(COLL_REDUCESCATTER, orc.I32, orc.SUM, count, ins, count * 4, graph=True)
+    for r in range(n):
+        assert ex.check(orc.I32, outs[r], orc.reduce_scatter_expected(orc.I32, orc.SUM, ins, r), exact=True) is None
 
 
 def test_registered_receive_buffers_are_written_directly(bed):

@@ -216,6 +216,26 @@ def _child(rank, nranks, device, conn, env):
                     comm.deregister(reg_handle)
                 reg_state = None
                 conn.send(("ok", None))
+            elif cmd == "second_comm":
+                # a second communicator over the same ranks, alive next to the first (a framework's DP + TP groups)
+                comm2 = ra.Communicator.init_rank(nranks, args, rank)
+                conn.send(("ok", comm2.count()))
+            elif cmd == "interleave":
+                # args: dict(dtype, op, count, a(bytes), b(bytes)): first(a) second(b) first(b) second(a) on one stream
+                a = args
+                ta = torch.from_numpy(np.frombuffer(a["a"], dtype=np.uint8).copy()).cuda()
+                tb = torch.from_numpy(np.frombuffer(a["b"], dtype=np.uint8).copy()).cuda()
+                outs = [torch.from_numpy(np.full(ta.numel(), 0xA5, dtype=np.uint8)).cuda() for _ in range(4)]
+                torch.cuda.synchronize()
+                for k, (c, src) in enumerate([(comm, ta), (comm2, tb), (comm, tb), (comm2, ta)]):
+                    c.all_reduce(src.data_ptr(), outs[k].data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                stream.synchronize()
+                errs = (comm.async_error(), comm2.async_error())
+                conn.send(("ok", (errs, [o.cpu().numpy().tobytes() for o in outs])))
+            elif cmd == "second_destroy":
+                comm2.destroy()
+                comm2 = None
+                conn.send(("ok", None))
             elif cmd == "plan":
                 conn.send(("ok", comm.plan_info(*args)))
             elif cmd == "destroy":
@@ -314,6 +334,21 @@ class TestBed:
                 break          # a second in-place run would reduce the first one's output
         self._all("reg_release", [None] * self.nranks)
         return results
+
+    def run_two_comms(self, dtype, op, count, ins_a, ins_b):
+        """Four all-reduces alternating between the bed's communicator and a second one over the same ranks.
+        Returns per rank the four outputs [first(a), second(b), first(b), second(a)]."""
+        if not self.inited:
+            self.init_comms()
+        self.conns[0].send(("uid", None))
+        uid = self._recv(0)
+        assert self._all("second_comm", [uid] * self.nranks) == [self.nranks] * self.nranks
+        res = self._all("interleave", [dict(dtype=dtype, op=op, count=count, a=np.ascontiguousarray(ins_a[r]).tobytes(),
+                                            b=np.ascontiguousarray(ins_b[r]).tobytes()) for r in range(self.nranks)])
+        self._all("second_destroy", [None] * self.nranks)
+        for r, (errs, _) in enumerate(res):
+            assert errs == (0, 0), f"rank {r}: asynchronous errors {errs}"
+        return [[np.frombuffer(b, dtype=np.uint8) for b in outs] for _, outs in res]
 
     def command(self, rank, cmd, args=None):
         self.conns[rank].send((cmd, args))
