@@ -878,31 +878,78 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
   const size_t nbytes = w.count * w.elemSize;          // per rank
   const size_t chunkB = w.chunkElems * w.elemSize;
   const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  // Registered receive buffers (zero-copy all-gather).  A spreader may write into a peer's recvbuff only once that
+  // peer's launch has begun, and it has to learn where the buffer is: for blocks of RA_AG_ANNOUNCE_BYTES and more
+  // (a rule every rank evaluates alike) each gather workgroup first sends its registration word to every peer on the
+  // otherwise idle kind-0 flags, and each spread workgroup waits for those words before its first chunk.  A spreader
+  // that has the registration mapped then writes its block straight into the peer's recvbuff and says so with its
+  // first post; that peer's gather role has nothing to copy for it.
+  const bool announce = !cx.comm->netMode && nbytes >= RA_AG_ANNOUNCE_BYTES && (size_t)cx.ch < nRounds;
+  if (announce && role == 1) {
+    if (cx.tid < n) cx.sh->auxOut[cx.tid] = w.regWord;
+    cx.auxSend = 1;
+    cx.step(0, 0, peers, 0, []() {});
+    cx.auxSend = 0;
+  } else if (announce) {
+    cx.auxRecv = 1;
+    cx.step(peers, 0, 0, 0, [&]() {
+      if (cx.tid < n && cx.tid != r) {
+        const int p = cx.tid;
+        const uint64_t W = w.peerRegs ? cx.sh->auxIn[p] : 0;
+        uint64_t base = 0;
+        if ((W & RA_REG_VALID) && RA_REG_IDX(W) < RA_MAX_REGS) {
+          const RaRegSlot slot = cx.comm->regTable[p * RA_MAX_REGS + RA_REG_IDX(W)];
+          if (slot.base && slot.serial == RA_REG_SERIAL(W)) base = slot.base + RA_REG_OFF(W);
+        }
+        cx.sh->directBase[p] = base;
+        cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
+      }
+    });
+    cx.auxRecv = 0;
+  }
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+    const bool first = g == (size_t)cx.ch;
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     if (role == 0) {
+      cx.auxSend = announce && first;
       cx.step(0, 0, peers, 1, [&]() {
         RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = w.send + off;
-        int k = 0;
+        int k = 0, nDirect = 0;
         char* mine = w.recv + (size_t)r * nbytes + off;
         if (mine != w.send + off) a.dst[k++] = mine;
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
+        for (int i = 1; i < n; i++) {
+          const int p = (r + i) % n;
+          const uint64_t base = cx.sh->directBase[p];
+          a.sysMask |= 1u << k;
+          a.dst[k++] = base ? (char*)base + (size_t)r * nbytes + off : cx.sendSlot(p, 1);
+          nDirect += base != 0;
+        }
         a.nd = k;
         copyWG(a, nb, cx.tid, cx.nthr);
+        if (announce && cx.tid == 0) {
+          if (nDirect) __hip_atomic_fetch_add(&cx.comm->stats[0], (uint64_t)nDirect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (n - 1 - nDirect) __hip_atomic_fetch_add(&cx.comm->stats[1], (uint64_t)(n - 1 - nDirect), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       });
     } else {
+      cx.auxRecv = announce && first && w.regWord != 0;
       cx.step(peers, 1, 0, 0, [&]() {
-        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        // blocks a peer wrote straight into recvbuff need no copy
+        RcArgs pa; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        int np = 0;
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
-          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = w.recv + (size_t)p * nbytes + off;
+          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
+          pa.src[np] = cx.recvSlot(p, 1); pa.dst[np] = w.recv + (size_t)p * nbytes + off; np++;
         }
-        pairCopyWG(pa, nb, cx.tid, cx.nthr);
+        pa.ns = np; pa.nd = np;
+        if (np) pairCopyWG(pa, nb, cx.tid, cx.nthr);
       });
     }
   }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // Broadcast (bytes): the root spreads each chunk into every peer's window (and into its own recvbuff

@@ -20,6 +20,9 @@
 namespace {
 
 #define RA_BOARD_MAGIC 0x52414247u
+// Largest peer allocation mapped through HIP IPC.  With 2 GiB allocations hipIpcOpenMemHandle did not return within a
+// minute (ROCm 7.2, two processes on one MI355X); 1.5 GiB maps in milliseconds.
+#define RA_REG_MAX_IPC_BYTES (1ull << 31)
 
 // One published registration.  `serial` is a per-entry sequence lock: 0 while the owner rewrites the
 // entry (and for an empty one), a fresh non-zero value once it is complete.
@@ -95,6 +98,10 @@ void* acquireMap(RaRegState* s, int p, const RegEntry& e, bool samePid) {
   m.base = e.base; m.refs = 1; m.ipc = !samePid; m.mapped = nullptr;
   if (samePid) {
     m.mapped = (void*)(uintptr_t)e.base;
+  } else if (e.size >= RA_REG_MAX_IPC_BYTES) {
+    RA_INFO("rank %d's registered allocation of %llu bytes is not mapped (allocations of 2 GiB and more did not come back from "
+            "hipIpcOpenMemHandle when tried): its pieces keep going through the FIFO", p, (unsigned long long)e.size);
+    return nullptr;
   } else {
     hipError_t err = hipIpcOpenMemHandle(&m.mapped, e.handle, hipIpcMemLazyEnablePeerAccess);
     if (err != hipSuccess) {

@@ -189,27 +189,57 @@ def _child(rank, nranks, device, conn, env):
                     res = res[:a["out_bytes"]]
                 conn.send(("ok", (err, res.tobytes())))
             elif cmd == "reg_prepare":
-                # args: dict(dtype, count, input(bytes), in_place, register_recv): buffers that stay alive across commands
+                # args: dict(coll, dtype, count, input(bytes), in_place, register_recv): buffers that stay alive across commands
                 a = args
                 es = ra.TYPE_SIZE[a["dtype"]]
                 host_in = np.frombuffer(a["input"], dtype=np.uint8)
-                reg_in = torch.from_numpy(host_in.copy()).cuda()
-                reg_out = reg_in if a["in_place"] else torch.from_numpy(np.full(host_in.size, 0xA5, dtype=np.uint8)).cuda()
+                if a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER:
+                    image = np.full(host_in.size * nranks, 0xA5, dtype=np.uint8)
+                    if a["in_place"]:
+                        image[rank * host_in.size:(rank + 1) * host_in.size] = host_in
+                    reg_out = torch.from_numpy(image).cuda()
+                    reg_in = reg_out[rank * host_in.size:(rank + 1) * host_in.size] if a["in_place"] else torch.from_numpy(host_in.copy()).cuda()
+                else:
+                    reg_in = torch.from_numpy(host_in.copy()).cuda()
+                    reg_out = reg_in if a["in_place"] else torch.from_numpy(np.full(host_in.size, 0xA5, dtype=np.uint8)).cuda()
                 torch.cuda.synchronize()
-                reg_handle = comm.register(reg_out.data_ptr(), host_in.size) if a["register_recv"] else None
+                reg_handle = comm.register(reg_out.data_ptr(), reg_out.numel()) if a["register_recv"] else None
                 reg_state = (a, reg_in, reg_out, reg_handle)
                 conn.send(("ok", None))
             elif cmd == "reg_run":
                 a, reg_in, reg_out, reg_handle = reg_state
                 before = comm.stats()
+                gather = a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER
                 if not a["in_place"]:
                     reg_out.fill_(0x5A)
                     torch.cuda.synchronize()
-                comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                    # Push the poisoned lines out of this GPU's caches (512 MiB of other traffic) before the launch.
+                    # With several ranks on one GPU the peers write through IPC mappings of the same device memory, and
+                    # in some process states (seen after managed allocations followed by a graph capture) such writes
+                    # are not coherent with lines the owner's earlier kernels left in its L2s: neither write-back nor
+                    # invalidate instructions helped, eviction does.
+                    sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+                    sweep.fill_(1)
+                    int(sweep.sum().item())
+                    del sweep
+                    torch.cuda.synchronize()
+                if gather:
+                    comm.all_gather(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], stream)
+                else:
+                    comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
                 stream.synchronize()
                 after = comm.stats()
                 conn.send(("ok", (comm.async_error(), reg_out.cpu().numpy().tobytes(),
                                   {k: after[k] - before[k] for k in after})))
+            elif cmd == "reg_reread":
+                # read the receive buffer again after sweeping this GPU's caches with 512 MiB of other traffic
+                a, reg_in, reg_out, reg_handle = reg_state
+                sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+                sweep.fill_(1)
+                int(sweep.sum().item())
+                del sweep
+                torch.cuda.synchronize()
+                conn.send(("ok", reg_out.cpu().numpy().tobytes()))
             elif cmd == "reg_release":
                 a, reg_in, reg_out, reg_handle = reg_state
                 if reg_handle is not None:
@@ -275,6 +305,7 @@ class TestBed:
             self.conns.append(parent)
             self.procs.append(p)
         self.inited = False
+        self.stale_reads = []
 
     def _recv(self, r):
         if not self.conns[r].poll(self.timeout):
@@ -316,21 +347,36 @@ class TestBed:
             assert err == 0, f"rank {r}: asynchronous error {err}"
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
 
-    def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1):
-        """All-reduce on buffers that stay allocated (and registered on `register_ranks`, default all) across `runs`
-        launches.  Returns, per run, (outputs per rank, stats deltas per rank)."""
+    def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1, coll=COLL_ALLREDUCE,
+                       want=None):
+        """All-reduce (or all-gather) on buffers that stay allocated (and registered on `register_ranks`, default all) across `runs`
+        launches.  Returns, per run, (outputs per rank, stats deltas per rank).
+
+        `want` (the expected receive buffer, same on every rank): when a rank's output differs from it only where the
+        poison written before the launch is still visible, the buffers are read a second time after this GPU's caches
+        were swept, those bytes are returned instead and the ranks are noted in `self.stale_reads`.  (On some boxes a
+        write from another process on the SAME GPU through an IPC mapping is not seen by the owner's next read while
+        an older copy of the line sits in a cache: an artefact of running several ranks on one GPU.)"""
         if not self.inited:
             self.init_comms()
         regs = set(range(self.nranks)) if register_ranks is None else set(register_ranks)
-        self._all("reg_prepare", [dict(dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
+        self._all("reg_prepare", [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                                        in_place=in_place, register_recv=r in regs) for r in range(self.nranks)])
         results = []
         for _ in range(runs):
             res = self._all("reg_run", [None] * self.nranks)
             for r, (err, _, _) in enumerate(res):
                 assert err == 0, f"rank {r}: asynchronous error {err}"
-            results.append(([np.frombuffer(b, dtype=np.uint8) for _, b, _ in res], [st for _, _, st in res]))
-            if in_place:
+            outs = [np.frombuffer(b, dtype=np.uint8) for _, b, _ in res]
+            if want is not None and not in_place:
+                w = np.ascontiguousarray(want).view(np.uint8).ravel()
+                stale = [r for r in range(self.nranks)
+                         if outs[r].size == w.size and (outs[r] != w).any() and (outs[r][outs[r] != w] == 0x5A).all()]
+                if stale:
+                    outs = [np.frombuffer(b, dtype=np.uint8) for b in self._all("reg_reread", [None] * self.nranks)]
+                    self.stale_reads.append(stale)
+            results.append((outs, [st for _, _, st in res]))
+            if in_place and coll == COLL_ALLREDUCE:
                 break          # a second in-place run would reduce the first one's output
         self._all("reg_release", [None] * self.nranks)
         return results
