@@ -18,6 +18,18 @@ import numpy as np
 COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE = 0, 1, 2, 3, 4
 
 
+def _sweep(torch):
+    """Push whatever earlier kernels and copies left in this GPU's caches out of them (512 MiB of other traffic).
+    With several processes on one GPU, older copies of 128-byte lines were seen to resurface after a newer write on
+    some boxes (tools/torch_fill_copy_probe.py shows it without this library); the protocol under test does not depend
+    on cache residue, so the bed removes it after preparing buffers and before launching."""
+    sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    sweep.fill_(1)
+    int(sweep.sum().item())
+    del sweep
+    torch.cuda.synchronize()
+
+
 def _child(rank, nranks, device, conn, env):
     try:
         os.environ.update(env)
@@ -137,6 +149,8 @@ def _child(rank, nranks, device, conn, env):
                     user_op = comm.create_premul_sum(a["premul"], a["dtype"])
                     op = user_op
                 torch.cuda.synchronize()
+                if not a.get("managed"):
+                    _sweep(torch)
 
                 def issue():
                     if a["coll"] == COLL_ALLREDUCE:
@@ -213,16 +227,9 @@ def _child(rank, nranks, device, conn, env):
                 if not a["in_place"]:
                     reg_out.fill_(0x5A)
                     torch.cuda.synchronize()
-                    # Push the poisoned lines out of this GPU's caches (512 MiB of other traffic) before the launch.
-                    # With several ranks on one GPU the peers write through IPC mappings of the same device memory, and
-                    # in some process states (seen after managed allocations followed by a graph capture) such writes
-                    # are not coherent with lines the owner's earlier kernels left in its L2s: neither write-back nor
-                    # invalidate instructions helped, eviction does.
-                    sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
-                    sweep.fill_(1)
-                    int(sweep.sum().item())
-                    del sweep
-                    torch.cuda.synchronize()
+                    # In some process states (seen after managed allocations followed by a graph capture) a peer's
+                    # write through its IPC mapping is not coherent with lines the owner's kernels left in its L2s.
+                    _sweep(torch)
                 if gather:
                     comm.all_gather(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], stream)
                 else:
@@ -234,11 +241,7 @@ def _child(rank, nranks, device, conn, env):
             elif cmd == "reg_reread":
                 # read the receive buffer again after sweeping this GPU's caches with 512 MiB of other traffic
                 a, reg_in, reg_out, reg_handle = reg_state
-                sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
-                sweep.fill_(1)
-                int(sweep.sum().item())
-                del sweep
-                torch.cuda.synchronize()
+                _sweep(torch)
                 conn.send(("ok", reg_out.cpu().numpy().tobytes()))
             elif cmd == "reg_release":
                 a, reg_in, reg_out, reg_handle = reg_state
