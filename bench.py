@@ -74,7 +74,12 @@ def main():
         # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
         os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // per_gpu)))
 
+    out = sys.stdout
     if n > 1:
+        # gloo reports its connections on file descriptor 1: keep the real stdout for the one JSON line and send
+        # everything else to stderr
+        out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=n)
 
@@ -88,13 +93,33 @@ def main():
     S = args.bytes                                   # bytes per rank (all-reduce) / per rank block
     count = S // es
 
+    def agree(err):
+        """Every rank learns whether any rank failed; rank 0 then prints a line that says why and all leave."""
+        if n == 1:
+            if err:
+                sys.exit(err)
+            return
+        errs = [None] * n
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            if rank == 0:
+                print(json.dumps({"metric": "AllReduce bus-bandwidth GB/s, 1 GiB fp32 sum", "value": None, "unit": "GB/s",
+                                  "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                                  "error": {str(r): e for r, e in enumerate(errs) if e}}), file=out, flush=True)
+            sys.exit(1)
+
     # communicator: unique id from rank 0 over gloo (what ncclGetUniqueId is for)
-    if n > 1:
-        uid = [ra.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        comm = ra.Communicator.init_rank(n, uid[0], rank)
-    else:
-        comm = ra.Communicator.init_all(1, [dev])[0]
+    err, comm = None, None
+    try:
+        if n > 1:
+            uid = [ra.get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = ra.Communicator.init_rank(n, uid[0], rank)
+        else:
+            comm = ra.Communicator.init_all(1, [dev])[0]
+    except ra.NcclError as e:
+        err = f"communicator set-up on device {dev}: {e}"
+    agree(err)
 
     # synthetic random bucket, seed 0x5EED0000 + rank, uniform [-1, 1)
     gen = torch.Generator(device="cuda")
@@ -121,9 +146,15 @@ def main():
         else:
             comm.all_gather(sendbuf, recvbuf, count, dt_code, stream)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+    try:
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if comm.async_error() != 0:
+            err = f"asynchronous error {comm.async_error()} during warm-up: {ra.lib().ncclGetLastError(None).decode()}"
+    except (ra.NcclError, RuntimeError) as e:
+        err = f"warm-up: {e}"
+    agree(err)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -239,7 +270,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out, flush=True)
 
 
 if __name__ == "__main__":
