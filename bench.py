@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="bucket size in bytes (default 1 GiB)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
-    ap.add_argument("--coll", default="allreduce", choices=["allreduce", "reducescatter", "allgather"])
+    ap.add_argument("--coll", default="allreduce", choices=["allreduce", "reducescatter", "allgather", "broadcast", "reduce"])
     ap.add_argument("--in-place", action="store_true")
     ap.add_argument("--register", action="store_true",
                     help="ncclCommRegister the receive buffer first (zero-copy gather phase); off in the default run")
@@ -124,7 +124,7 @@ def main():
     # synthetic random bucket, seed 0x5EED0000 + rank, uniform [-1, 1)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(0x5EED0000 + rank)
-    if args.coll == "allreduce":
+    if args.coll in ("allreduce", "broadcast", "reduce"):
         in_elems, out_elems = count, count
     elif args.coll == "reducescatter":
         in_elems, out_elems = count * n, count
@@ -143,6 +143,10 @@ def main():
             comm.all_reduce(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
         elif args.coll == "reducescatter":
             comm.reduce_scatter(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
+        elif args.coll == "broadcast":
+            comm.broadcast(sendbuf, recvbuf, count, dt_code, 0, stream)
+        elif args.coll == "reduce":
+            comm.reduce(sendbuf, recvbuf, count, dt_code, ra.ncclSum, 0, stream)
         else:
             comm.all_gather(sendbuf, recvbuf, count, dt_code, stream)
 
@@ -198,6 +202,10 @@ def main():
         algbw = S / per_step / 1e9
         factor = 2.0 * (n - 1) / n
         link_bytes = factor * S
+    elif args.coll in ("broadcast", "reduce"):
+        algbw = S / per_step / 1e9
+        factor = 1.0
+        link_bytes = (n - 1) * S                       # what leaves (or reaches) the root
     else:
         total = S * n
         algbw = total / per_step / 1e9
@@ -232,7 +240,7 @@ def main():
                                + ("" if n > 1 else " (1 rank: the reference path is a device copy; value is its S/t)"),
                    "ranks": n, "ranks_per_gpu": (n + ndev - 1) // ndev, "algbw_GBps": round(algbw, 3),
                    "registered_recvbuff": bool(reg_handle), "gather_phase_pieces": comm.stats() if n > 1 else None,
-                   "plan": comm.plan_info(0 if args.coll == "allreduce" else 1 if args.coll == "reducescatter" else 2,
+                   "plan": comm.plan_info({"allreduce": 0, "reducescatter": 1, "allgather": 2, "broadcast": 3, "reduce": 4}[args.coll],
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,
         "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",

@@ -69,6 +69,9 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
 #define RA_LL_DEFAULT_BYTES (512u << 10)   // largest payload that takes the low-latency protocol unless RCCL_AMD_LL_MAX_BYTES says otherwise
 #define RA_LL_GRID 16                  // workgroups of every low-latency launch (fixed: each keeps its own epoch)
 #define RA_LL_THREADS 1024
+// Broadcast and reduce put one presence line per workgroup in the tail of a sender's line buffer; their payloads stay at
+// or below RA_LL_DEFAULT_BYTES, so data lines never reach it.
+#define RA_LL_TOKEN_LINE ((size_t)RA_LL_MAX_BYTES / 8 - RA_LL_GRID)
 __host__ __device__ inline size_t raLLOffset(const RaWindowLayout& l, int buf, int sender) {
   return l.llOffset + ((size_t)buf * l.nRanks + sender) * l.llBytes;
 }

@@ -193,7 +193,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e;
-  if (p.proto == 1 && a.coll == RA_COLL_ALLGATHER) {
+  if (p.proto == 1 && (a.coll == RA_COLL_ALLGATHER || a.coll == RA_COLL_BROADCAST)) {
     w.count = a.count * es;                                // bytes: the copy is the same for every element type
     e = raLaunchLL(c->devComm, w, ncclInt8, RA_OP_SUM, a.stream);
   } else if (p.proto == 1) {
@@ -294,15 +294,16 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // Small all-reduces on the all-pairs schedule take the one-shot low-latency protocol
   // (the reference switches to LL below 256-512 KiB, src/graph/tuning.cc:632-671).
   // Reduce-scatter and all-gather take it up to the same payload per rank: like the all-reduce they need every
-  // peer's lines to finish, which is the flow control of the two alternating line buffers (broadcast and reduce
-  // do not have that property and stay on the FIFO).
-  const bool llColl = coll == RA_COLL_ALLREDUCE || coll == RA_COLL_REDUCESCATTER || coll == RA_COLL_ALLGATHER;
+  // peer's lines to finish, which is the flow control of the two alternating line buffers.  Broadcast and reduce
+  // get that property from one presence line per peer and take it up to RA_LL_DEFAULT_BYTES.
+  const bool rooted = coll == RA_COLL_BROADCAST || coll == RA_COLL_REDUCE;
   // Limit: measured switch-over with ranks sharing one GPU is above 1 MiB at 2 ranks (23 us against 37 us) and about
   // 1 MiB at 8; the one-shot exchange sends n-1 copies of the payload, so larger groups keep the smaller limit.
   static const long llEnv = []() { const char* e = getenv("RCCL_AMD_LL_MAX_BYTES"); return e ? atol(e) : 0L; }();
   size_t llMax = n <= 4 ? (size_t)RA_LL_MAX_BYTES : (size_t)RA_LL_DEFAULT_BYTES;
   if (llEnv > 0) llMax = llEnv > (long)RA_LL_MAX_BYTES ? (size_t)RA_LL_MAX_BYTES : (size_t)llEnv;
-  if (allowLL && llColl && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
+  if (rooted && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
+  if (allowLL && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
     p->proto = 1;
     p->nChannels = RA_LL_GRID;
     p->grid = RA_LL_GRID;

@@ -1297,6 +1297,11 @@ __device__ __forceinline__ bool llWaitLine(const RaDevComm* comm, const char* lp
 // All-reduce, reduce-scatter (rank p is sent block p) and all-gather (no fold: every sender's lines are copied
 // to its block of recvbuff; launched with T = int8 and a byte count).  All three need every peer's lines to
 // finish, which is what keeps any rank from running two launches ahead of another.
+// Broadcast (T = int8, byte count) and reduce move data along the root's links only, so they add a presence
+// token: every workgroup starts by writing one line to each peer (in the tail of its line buffer, which payloads
+// of at most RA_LL_DEFAULT_BYTES never reach) and ends by waiting for each peer's.  A token of launch e says its
+// sender has finished launch e-1, so "finishing a launch needs a line of that launch from every peer" holds for
+// them too and the two alternating buffers stay safe under any mix of collectives.
 template <typename T, int OP>
 __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDevComm* __restrict__ comm, RaWork w) {
   const int n = comm->nRanks, r = comm->rank;
@@ -1306,10 +1311,19 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
   const bool scatter = w.coll == RA_COLL_REDUCESCATTER, gather = w.coll == RA_COLL_ALLGATHER;
+  const bool bcast = w.coll == RA_COLL_BROADCAST, toRoot = w.coll == RA_COLL_REDUCE;
+  const bool rooted = bcast || toRoot;
+  const int root = w.root;
   const size_t nUnits = (w.count * sizeof(T) + 7) / 8;
   const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
-  // 1. my contribution to everyone
-  for (size_t u = gtid; u < nUnits; u += gsize) {
+  const size_t tokenLine = RA_LL_TOKEN_LINE + blockIdx.x;
+  if (rooted && (int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line; line.x = 0; line.y = epoch; line.z = 0; line.w = epoch;
+    stSys((u32x4*)(comm->win[threadIdx.x] + raLLOffset(comm->lay, buf, r)) + tokenLine, line);
+  }
+  // 1. my contribution to everyone (broadcast: the root's only; reduce: to the root only)
+  const bool sends = !rooted || (bcast ? r == root : r != root);
+  for (size_t u = gtid; sends && u < nUnits; u += gsize) {
     uint64_t v = 0;
     if (!scatter) {
       v = llLoadUnit<T>(in, u, w.count);
@@ -1317,6 +1331,7 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
     }
     for (int i = 1; i < n; i++) {
       const int p = (r + i) % n;
+      if (toRoot && p != root) continue;
       if (scatter) {
         v = llLoadUnit<T>(in + (size_t)p * w.count, u, w.count);
         if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
@@ -1328,7 +1343,8 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   // 2. fold (or place) what arrives, in rank order
   bool dead = false;
   const T* mine = scatter ? in + (size_t)r * w.count : in;
-  for (size_t u = gtid; u < nUnits; u += gsize) {
+  const bool folds = !rooted || (toRoot && r == root);
+  for (size_t u = gtid; folds && u < nUnits; u += gsize) {
     uint64_t acc = 0;
     for (int q = 0; q < n; q++) {
       uint64_t x;
@@ -1346,6 +1362,21 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
     if (gather) continue;
     if (OP == RA_OP_SUMPOSTDIV) acc = llScale<T, false>(acc, w.opArg);
     if (!dead) llStoreUnit<T>(out, u, w.count, acc);
+  }
+  if (bcast) {
+    for (size_t u = gtid; u < nUnits; u += gsize) {
+      if (r == root) {
+        if (out != in) llStoreUnit<T>(out, u, w.count, llLoadUnit<T>(in, u, w.count));
+      } else {
+        u32x4 line;
+        llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, root) + u * 16, epoch, dead, line);
+        if (!dead) llStoreUnit<T>(out, u, w.count, (uint64_t)line.x | ((uint64_t)line.z << 32));
+      }
+    }
+  }
+  if (rooted && (int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line;
+    llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, (int)threadIdx.x) + tokenLine * 16, epoch, dead, line);
   }
   // 3. this workgroup has run one more launch (every thread is past its reads of the old value)
   __syncthreads();

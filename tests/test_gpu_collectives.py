@@ -144,17 +144,41 @@ def test_all_gather_cases(bed, algo):
 
 def test_broadcast_and_reduce(bed):
     """ncclBroadcast / ncclReduce (expected values as test/common/PrepDataFuncs.cpp:43-78 and :80-148):
-    every rank ends with the root's pattern; the root ends with the rank-order fold."""
-    bed.init_comms({"NCCL_ALGO": None})
+    every rank ends with the root's pattern; the root ends with the rank-order fold.  Payloads up to 512 KiB take
+    the low-latency protocol unless NCCL_PROTO=Simple; the larger ones the FIFO."""
+    n = bed.nranks
+    for proto in (None, "Simple"):
+        bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": proto})
+        assert bed.plan(COLL_BROADCAST, 53327, orc.F16)["proto"] == (1 if proto is None else 0)
+        assert bed.plan(COLL_REDUCE, 131073, orc.F32)["proto"] == 0
+        _broadcast_and_reduce_cases(bed)
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
+    # rooted low-latency launches between all-reduces, roots changing every launch: the line buffers' epochs stay in step
+    x = np.arange(3000, dtype=np.int32)
+    for k in range(6):
+        root = (3 * k + 1) % n
+        ins = [orc.fill_pattern(orc.I32, 3000, root if r == root else 100 + r) for r in range(n)]
+        outs = bed.run(COLL_BROADCAST, orc.I32, orc.SUM, 3000, ins, 12000, root=root, iters=2)
+        for r in range(n):
+            assert ex.check(orc.I32, outs[r], ins[root], exact=True) is None, (k, r)
+        outs = bed.run(COLL_REDUCE, orc.I32, orc.SUM, 3000, [x + r for r in range(n)], 12000, root=(root + 1) % n, iters=3)
+        assert np.array_equal(outs[(root + 1) % n].view(np.int32), n * x + n * (n - 1) // 2)
+        outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 3000, [x] * n, 12000)
+        for o in outs:
+            assert np.array_equal(o.view(np.int32), n * x)
+
+
+def _broadcast_and_reduce_cases(bed):
     n = bed.nranks
     for root in (0, n - 1):
-        for dt, count, in_place in ((orc.F32, 1048576, False), (orc.F16, 53327, False), (orc.I8, 1000003, True), (orc.F64, 4099, False)):
+        for dt, count, in_place in ((orc.F32, 1048576, False), (orc.F16, 53327, False), (orc.I8, 1000003, True), (orc.F64, 4099, False),
+                                    (orc.U8, 524288, True), (orc.U8, 3, False)):
             ins = [orc.fill_pattern(dt, count, root if r == root else 200 + r) for r in range(n)]   # only the root's input counts
             outs = bed.run(COLL_BROADCAST, dt, orc.SUM, count, ins, count * _es(dt), in_place=in_place, root=root)
             for r in range(n):
                 assert ex.check(dt, outs[r], ins[root], exact=True) is None, (root, orc.DT_NAMES[dt], count, r)
         for dt, op, count in ((orc.F32, orc.SUM, 1048576), (orc.I32, orc.PROD, 384), (orc.BF16, orc.MAX, 53327), (orc.U64, orc.AVG, 70001),
-                              (orc.F32, orc.AVG, 70001)):
+                              (orc.F32, orc.AVG, 70001), (orc.I8, orc.SUM, 1), (orc.F32, orc.SUM, 131072)):
             ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
             outs = bed.run(COLL_REDUCE, dt, op, count, ins, count * _es(dt), root=root)
             assert ex.check(dt, outs[root], orc.device_fold(dt, op, ins), exact=True) is None, (root, orc.DT_NAMES[dt], orc.OP_NAMES[op])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/latency_sweep.sh <ranks> : small-message time per operation, low-latency protocol against the FIFO protocol
 N=${1:-2}
-for COLL in allreduce reducescatter allgather; do
+for COLL in ${COLLS:-allreduce reducescatter allgather broadcast reduce}; do
   for B in 1024 65536 262144; do
     for PROTO in LL Simple; do
       NCCL_PROTO=$PROTO timeout -k 10 100 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
