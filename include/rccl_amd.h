@@ -105,7 +105,8 @@ ncclResult_t ncclMemAlloc(void** ptr, size_t size);                          /* 
 ncclResult_t ncclMemFree(void* ptr);                                         /* nccl.h.in:108 */
 /* Registers a device buffer with the communicator; local call, reference-counted per allocation
  * (src/register.cc:106-160).  An all-reduce whose recvbuff lies in a registered allocation on a rank
- * lets the other ranks write their finished pieces straight into it instead of through the FIFO. */
+ * lets the other ranks write their finished pieces straight into it instead of through the FIFO; so does an
+ * all-gather of at least 4 MiB per rank.  Allocations of 2 GiB and more are registered locally only. */
 ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle);   /* nccl.h.in:324 */
 ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle);                           /* nccl.h.in:330 */
 
