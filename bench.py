@@ -76,6 +76,7 @@ def main():
 
     out = sys.stdout
     if n > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # a failing rank says why on stderr
         # gloo reports its connections on file descriptor 1: keep the real stdout for the one JSON line and send
         # everything else to stderr
         out = os.fdopen(os.dup(1), "w")
