@@ -336,6 +336,14 @@ def test_hip_graph_capture_and_replay(bed):
     outs = bed.run(COLL_REDUCESCATTER, orc.I32, orc.SUM, count, ins, count * 4, graph=True)
     for r in range(n):
         assert ex.check(orc.I32, outs[r], orc.reduce_scatter_expected(orc.I32, orc.SUM, ins, r), exact=True) is None
+    # rooted low-latency launches replayed: their presence lines carry the replay's epoch as well
+    ins = [orc.fill_pattern(orc.I32, count, 7 if r == n - 1 else 100 + r) for r in range(n)]
+    outs = bed.run(COLL_BROADCAST, orc.I32, orc.SUM, count, ins, count * 4, root=n - 1, graph=True)
+    for r in range(n):
+        assert ex.check(orc.I32, outs[r], ins[n - 1], exact=True) is None
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    outs = bed.run(COLL_REDUCE, orc.F32, orc.SUM, count, ins, count * 4, root=0, graph=True)
+    assert ex.check(orc.F32, outs[0], orc.device_fold(orc.F32, orc.SUM, ins), exact=True) is None
 
 
 def _skip_if_stale_reads(bed):

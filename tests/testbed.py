@@ -171,11 +171,12 @@ def _child(rank, nranks, device, conn, env):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=stream):
                         issue()
-                    g.replay()
-                    stream.synchronize()
-                    out_view()[pad_r:pad_r + a["out_bytes"]].fill_(0x3C)
-                    torch.cuda.synchronize()
-                    g.replay()
+                    with torch.cuda.stream(stream):        # replays on the capture stream: no further hardware queue
+                        g.replay()
+                        stream.synchronize()
+                        out_view()[pad_r:pad_r + a["out_bytes"]].fill_(0x3C)
+                        stream.synchronize()
+                        g.replay()
                 with torch.cuda.stream(stream):
                     for _ in range(0 if a.get("graph") else a.get("iters", 1)):
                         if a["in_place"] and a.get("iters", 1) > 1:
@@ -296,7 +297,9 @@ class TestBed:
         ctx = mp.get_context("spawn")
         # Ranks that share a GPU share its 256 CUs: keep ranks x roles x channels workgroups resident.
         per_gpu = -(-nranks // len(devices))
-        base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "10000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60",
+        # (with 8 processes on one GPU single launches were seen to stall for 0.5-3 s, in steps of about half a second,
+        # while the driver rotated the processes' queues: the device-side wait limit leaves room for that)
+        base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "30000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60",
                     "RCCL_AMD_NCHANNELS": str(max(2, min(16, 64 // per_gpu)))}
         base_env.update(env or {})
         self.base_env = dict(base_env)
