@@ -42,7 +42,9 @@ def _child(rank, nranks, device, conn, env):
             cmd, args = conn.recv()
             if cmd == "stop":
                 break
-            if cmd == "uid":
+            if cmd == "ping":
+                conn.send(("ok", None))
+            elif cmd == "uid":
                 conn.send(("ok", ra.get_unique_id()))
             elif cmd == "init":
                 uid, init_env = args
@@ -312,10 +314,14 @@ class TestBed:
             self.procs.append(p)
         self.inited = False
         self.stale_reads = []
+        self.answered = set()
 
     def _recv(self, r):
-        if not self.conns[r].poll(self.timeout):
-            raise TimeoutError(f"rank {r} did not answer within {self.timeout}s")
+        # the first answer of a child includes its `import torch`, which can take minutes on a box that has just started
+        limit = self.timeout if r in self.answered else max(self.timeout, 400)
+        if not self.conns[r].poll(limit):
+            raise TimeoutError(f"rank {r} did not answer within {limit}s")
+        self.answered.add(r)
         status, val = self.conns[r].recv()
         if status != "ok":
             raise RuntimeError(f"rank {r} failed:\n{val}")
@@ -329,6 +335,8 @@ class TestBed:
     def init_comms(self, env=None):
         """(Re)create the communicators; `env` entries are set (None: unset) in every child first."""
         self.destroy_comms()
+        if len(self.answered) < self.nranks:
+            self._all("ping", [None] * self.nranks)      # every child is past its imports before any rank waits for the others
         self.conns[0].send(("uid", None))
         uid = self._recv(0)
         info = self._all("init", [(uid, env or {})] * self.nranks)
