@@ -366,6 +366,13 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       break;
     }
     if ((res = allocWindow(c)) != ncclSuccess) break;
+    if (c->lay.totalBytes >= (1ull << 31)) {
+      // hipIpcOpenMemHandle did not return for allocations of 2 GiB and more when tried (ROCm 7.2): refuse rather than hang
+      RA_WARN("the receive window would be %zu MiB; windows shared between processes must stay below 2 GiB "
+              "(fewer channels, NCCL_MAX_NCHANNELS, or a smaller NCCL_BUFFSIZE)", c->lay.totalBytes >> 20);
+      res = ncclInvalidUsage;
+      break;
+    }
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
     me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash();
