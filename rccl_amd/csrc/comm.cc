@@ -109,6 +109,23 @@ void makeLayout(ncclComm* c) {
   l.totalBytes = raLLOffset(l, 2, 0);
 }
 
+// Low-latency launches use 32 workgroups when every rank has a GPU to itself and 16 when ranks share one (8 ranks x 16
+// workgroups of 1024 threads still fit a GPU together); RCCL_AMD_LL_GRID overrides.  Every rank decides from the same data.
+void setLLGrid(ncclComm* c, bool shared) {
+  long g = envLong("RCCL_AMD_LL_GRID", shared ? RA_LL_GRID : RA_LL_MAX_GRID);
+  if (g < 1) g = 1;
+  if (g > RA_LL_MAX_GRID) g = RA_LL_MAX_GRID;
+  c->llGrid = (int)g;
+}
+
+uint64_t busIdOf(int device) {
+  char id[64] = "";
+  if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) { (void)hipGetLastError(); return (uint64_t)device + 1; }
+  uint64_t h = 1469598103934665603ull;
+  for (const char* p = id; *p; p++) h = (h ^ (uint64_t)(unsigned char)*p) * 1099511628211ull;
+  return h;
+}
+
 ncclResult_t allocWindow(ncclComm* c) {
   makeLayout(c);
   if (c->nRanks == 1) return ncclSuccess;
@@ -155,8 +172,8 @@ ncclResult_t buildDevComm(ncclComm* c) {
   const size_t nSteps = (size_t)c->lay.nChannels * c->nRanks * RA_NKINDS;
   RA_HIP(hipMalloc((void**)&c->steps, 2 * nSteps * sizeof(uint64_t)));
   RA_HIP(hipMemset(c->steps, 0, 2 * nSteps * sizeof(uint64_t)));
-  RA_HIP(hipMalloc((void**)&c->llEpoch, RA_LL_GRID * sizeof(uint32_t)));
-  RA_HIP(hipMemset(c->llEpoch, 0, RA_LL_GRID * sizeof(uint32_t)));
+  RA_HIP(hipMalloc((void**)&c->llEpoch, RA_LL_MAX_GRID * sizeof(uint32_t)));
+  RA_HIP(hipMemset(c->llEpoch, 0, RA_LL_MAX_GRID * sizeof(uint32_t)));
   RA_HIP(hipMalloc((void**)&c->regTable, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
   RA_HIP(hipMemset(c->regTable, 0, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
   RA_HIP(hipMalloc((void**)&c->stats, 32 * sizeof(uint64_t)));
@@ -272,6 +289,9 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
         return ncclInvalidArgument;
       }
   }
+  bool shared = false;
+  for (int i = 0; i < ndev; i++)
+    for (int j = 0; j < i; j++) shared = shared || devs[(size_t)j] == devs[(size_t)i];
   DeviceGuard guard;
   auto clique = std::make_shared<RaClique>();
   clique->nRanks = ndev;
@@ -285,6 +305,7 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
     cs[(size_t)i] = c;
     c->rank = i; c->nRanks = ndev; c->device = devs[(size_t)i]; c->clique = clique;
     readTunables(c);
+    setLLGrid(c, shared);
     if (hipSetDevice(c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
     res = allocWindow(c);
     clique->window[(size_t)i] = c->window;
@@ -313,6 +334,7 @@ struct PeerInfo {            // one per rank, all-gathered at init (cf. src/incl
   int32_t rank, pid, device, maxChannels;
   uint32_t slotBytes; int32_t nSlots;
   uint64_t hostHash;
+  uint64_t busId;            // hash of the device's PCI bus id: equal on two ranks = they share a GPU
   uint64_t windowPtr;        // meaningful inside the owner's process only
   hipIpcMemHandle_t handle;
   int32_t haveHandle, pad;
@@ -375,7 +397,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
     }
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
-    me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash();
+    me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash(); me.busId = busIdOf(c->device);
     me.windowPtr = (uint64_t)(uintptr_t)c->window;
     me.haveHandle = hipIpcGetMemHandle(&me.handle, c->window) == hipSuccess;
     (void)hipGetLastError();
@@ -419,6 +441,12 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       }
     }
     if (res != ncclSuccess) break;
+    {
+      bool shared = false;
+      for (int p = 0; p < nranks; p++)
+        for (int q = 0; q < p; q++) shared = shared || all[(size_t)p].busId == all[(size_t)q].busId;
+      setLLGrid(c, shared);
+    }
     if ((res = raRegInit(c, key)) != ncclSuccess) break;
     if ((res = buildDevComm(c)) != ncclSuccess) break;
     res = c->boot.barrier();      // nobody launches before every window is mapped everywhere

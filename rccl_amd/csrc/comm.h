@@ -46,6 +46,7 @@ struct ncclComm {
   int blockThreads = 512;
   int algoEnv = -1;          // NCCL_ALGO: -1 unset
   bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol
+  int llGrid = RA_LL_GRID;   // workgroups of a low-latency launch (the same on every rank of the communicator)
   size_t minChunkBytes = 32 << 10;
 
   // device resources

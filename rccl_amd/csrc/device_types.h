@@ -67,11 +67,12 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
 // store and the receiver needs no separate flag round trip.
 #define RA_LL_MAX_BYTES (1u << 20)     // payload one sender's line buffer has room for
 #define RA_LL_DEFAULT_BYTES (512u << 10)   // largest payload that takes the low-latency protocol unless RCCL_AMD_LL_MAX_BYTES says otherwise
-#define RA_LL_GRID 16                  // workgroups of every low-latency launch (fixed: each keeps its own epoch)
+#define RA_LL_GRID 16                  // workgroups of a low-latency launch when ranks share a GPU (8 ranks x 16 stay resident)
+#define RA_LL_MAX_GRID 32              // ... and when every rank has its own GPU; fixed per communicator (each workgroup keeps its own epoch)
 #define RA_LL_THREADS 1024
 // Broadcast and reduce put one presence line per workgroup in the tail of a sender's line buffer; their payloads stay at
 // or below RA_LL_DEFAULT_BYTES, so data lines never reach it.
-#define RA_LL_TOKEN_LINE ((size_t)RA_LL_MAX_BYTES / 8 - RA_LL_GRID)
+#define RA_LL_TOKEN_LINE ((size_t)RA_LL_MAX_BYTES / 8 - RA_LL_MAX_GRID)
 __host__ __device__ inline size_t raLLOffset(const RaWindowLayout& l, int buf, int sender) {
   return l.llOffset + ((size_t)buf * l.nRanks + sender) * l.llBytes;
 }
@@ -99,7 +100,7 @@ struct RaDevComm {
   char* win[RA_MAX_RANKS];    // win[rank] is local; the others are peer mappings
   uint64_t* sendStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has published
   uint64_t* recvStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has consumed
-  uint32_t* llEpoch;          // [RA_LL_GRID] launches each low-latency workgroup has run
+  uint32_t* llEpoch;          // [RA_LL_MAX_GRID] launches each low-latency workgroup has run
   uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks

@@ -313,8 +313,10 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
 }
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
-  return raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
-                   c->blockThreads, c->allowLL && !c->net, p);
+  RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
+                     c->blockThreads, c->allowLL && !c->net, p));
+  if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }
+  return ncclSuccess;
 }
 
 int raGroupDepth() { return tGroupDepth; }

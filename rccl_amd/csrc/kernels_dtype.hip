@@ -44,7 +44,7 @@ static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int b
 }
 template <int OP>
 static hipError_t llOp(const RaDevComm* comm, const RaWork& w, hipStream_t s) {
-  hipLaunchKernelGGL((raLLAllReduceKernel<elem_t, OP>), dim3(RA_LL_GRID), dim3(RA_LL_THREADS), 0, s, comm, w);
+  hipLaunchKernelGGL((raLLAllReduceKernel<elem_t, OP>), dim3(w.nChannels), dim3(RA_LL_THREADS), 0, s, comm, w);
   return hipGetLastError();
 }
 template <int OP>

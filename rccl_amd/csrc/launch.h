@@ -6,7 +6,7 @@
 // grid = roles * w.nChannels workgroups of `block` threads on stream s.
 hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int op, int grid, int block, hipStream_t s);
 
-// One-shot low-latency all-reduce (payload <= RA_LL_MAX_BYTES): RA_LL_GRID x RA_LL_THREADS threads.
+// One-shot low-latency collectives (payload <= RA_LL_MAX_BYTES): w.nChannels (<= RA_LL_MAX_GRID) x RA_LL_THREADS threads.
 hipError_t raLaunchLL(const RaDevComm* comm, const RaWork& w, int dtype, int op, hipStream_t s);
 
 // Local kernels run RA_LOCAL_THREADS threads per workgroup; one workgroup moves RA_LOCAL_TILE_BYTES of
