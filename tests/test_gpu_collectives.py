@@ -371,6 +371,12 @@ def test_registered_receive_buffers_are_written_directly(bed):
         for r in range(n):
             assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
             assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    # captured into a hipGraph after the first (eager) launch mapped the registrations: replays write directly too
+    runs = bed.run_registered(orc.F32, orc.SUM, count, ins, runs=2, want=want, graph=True)
+    for outs, stats in runs:
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+            assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == 0, (r, stats[r])
     # only rank 0 registered: every other rank writes one of its n-1 pieces per round directly
     (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[0], want=want)
     for r in range(n):

@@ -233,10 +233,28 @@ def _child(rank, nranks, device, conn, env):
                     # In some process states (seen after managed allocations followed by a graph capture) a peer's
                     # write through its IPC mapping is not coherent with lines the owner's kernels left in its L2s.
                     _sweep(torch)
-                if gather:
-                    comm.all_gather(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], stream)
+                def launch():
+                    if gather:
+                        comm.all_gather(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], stream)
+                    else:
+                        comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+
+                if args and args.get("graph"):
+                    # capture the launch on the registered buffers and replay it twice (a framework's steady state);
+                    # the registrations were mapped by an earlier eager launch
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=stream):
+                        launch()
+                    with torch.cuda.stream(stream):
+                        g.replay()
+                        stream.synchronize()
+                        if not a["in_place"]:
+                            reg_out.fill_(0x3C)
+                            stream.synchronize()
+                            _sweep(torch)
+                        g.replay()
                 else:
-                    comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                    launch()
                 stream.synchronize()
                 after = comm.stats()
                 conn.send(("ok", (comm.async_error(), reg_out.cpu().numpy().tobytes(),
@@ -362,9 +380,10 @@ class TestBed:
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
 
     def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1, coll=COLL_ALLREDUCE,
-                       want=None):
+                       want=None, graph=False):
         """All-reduce (or all-gather) on buffers that stay allocated (and registered on `register_ranks`, default all) across `runs`
-        launches.  Returns, per run, (outputs per rank, stats deltas per rank).
+        launches.  Returns, per run, (outputs per rank, stats deltas per rank).  `graph`: every run after the first is
+        captured into a hipGraph and replayed twice instead of being launched directly.
 
         `want` (the expected receive buffer, same on every rank): when a rank's output differs from it only where the
         poison written before the launch is still visible, the buffers are read a second time after this GPU's caches
@@ -377,8 +396,8 @@ class TestBed:
         self._all("reg_prepare", [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                                        in_place=in_place, register_recv=r in regs) for r in range(self.nranks)])
         results = []
-        for _ in range(runs):
-            res = self._all("reg_run", [None] * self.nranks)
+        for k in range(runs):
+            res = self._all("reg_run", [dict(graph=graph and k > 0)] * self.nranks)
             for r, (err, _, _) in enumerate(res):
                 assert err == 0, f"rank {r}: asynchronous error {err}"
             outs = [np.frombuffer(b, dtype=np.uint8) for _, b, _ in res]
