@@ -268,6 +268,11 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   size_t chunk;
   if (rounds) {
     chunk = alignUp(divUp(perOwner, nCh * rounds), unit);
+  } else if (n == 2) {
+    // Two ranks: a step moves one piece, and below a full slot its cost is mostly fixed (flag round trip, waiting for
+    // the stores to be acknowledged), so one round with the largest piece that fits beats any pipelining
+    // (ranks sharing one GPU: 8 MiB 91 -> 53 us, 16 MiB 104 -> 78 us, 128 MiB 371 -> 344 us; equal from 256 MiB on).
+    chunk = alignUp(divUp(perOwner, nCh), unit);
   } else {
     chunk = alignUp(divUp(perOwner, nCh * 4), unit);
     const size_t big = (256u << 10) / es;

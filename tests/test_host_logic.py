@@ -30,9 +30,9 @@ def test_allreduce_plan_geometry(n, dt, count):
 
 
 def test_plan_round_and_row_rules():
-    """Chunks are whole 1 KiB rows once they exceed the minimum; a channel gets about four rounds, eight
-    where four would need chunks above 256 KiB; small counts use only as many channels as have a full
-    minimum chunk each."""
+    """Chunks are whole 1 KiB rows once they exceed the minimum; with more than two ranks a channel gets about
+    four rounds, eight where four would need chunks above 256 KiB; with two ranks one round of the largest piece
+    that fits a slot; small counts use only as many channels as have a full minimum chunk each."""
     f32 = ra.ncclFloat32
     # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of ~293 KiB
     big = ra.plan_for_config(8, 0, 1 << 28, f32, max_channels=56)
@@ -42,9 +42,12 @@ def test_plan_round_and_row_rules():
     assert rounds == 8
     # 1 GiB, 2 ranks, 32 channels: the slot bounds the chunk (512 KiB)
     assert ra.plan_for_config(2, 0, 1 << 28, f32, max_channels=32)["chunkElems"] == (512 << 10) // 4
-    # 16 MiB, 2 ranks: four rounds of 64 KiB stay (eight rounds of 32 KiB were measured slower)
+    # 16 MiB, 2 ranks: one round of 256 KiB per channel (with two ranks a step's cost is mostly fixed below a full slot)
     mid = ra.plan_for_config(2, 0, 1 << 22, f32, max_channels=32)
-    assert mid["nChannels"] == 32 and mid["chunkElems"] == 16384
+    assert mid["nChannels"] == 32 and mid["chunkElems"] == 65536
+    # 16 MiB, 4 ranks: four rounds of 32 KiB stay (more ranks: a step moves n-1 pieces and pipelining pays)
+    mid4 = ra.plan_for_config(4, 0, 1 << 22, f32, max_channels=32)
+    assert mid4["nChannels"] == 32 and mid4["chunkElems"] == 8192
     # exactly 16 minimum chunks per rank pair -> 16 channels; one element more opens a 17th with a 4-element tail
     assert ra.plan_for_config(2, 0, 1 << 18, f32, max_channels=32)["nChannels"] == 16
     edge = ra.plan_for_config(2, 0, (1 << 18) + 1, f32, max_channels=32)
