@@ -12,9 +12,12 @@ synthetic random bucket already resident in HBM.  Rank 0 prints one JSON line:
   roofline   the dominant kernel's algorithmic bytes per launch / its average duration
              (HIP events on the launch stream) against the bound that applies:
              n = 1: HBM, 2*S bytes per launch, peak 8000 GB/s;
-             n > 1: xGMI, 2(n-1)/n*S bytes leave each GPU per launch, peak (n-1) links x 153 GB/s
-  cpu_baseline  rank 0, n = 1 only: the oracle's OpenMP element-wise sum over the same bucket on
-             the box's host cores (a reported baseline, not a target)
+             n > 1, one rank per GPU: xGMI, 2(n-1)/n*S bytes leave each GPU per launch, peak (n-1) links x 153 GB/s;
+             n > 1, several ranks on one GPU (loop-back, no link is used): HBM, the design's
+             2S + 4(n-1)/n*S bytes per rank (2(n-1)/n*S less with a registered receive buffer) x ranks on the GPU
+  cpu_baseline  rank 0, every n: the oracle's OpenMP element-wise sum of the n host buckets (regenerated
+             from the same seeds) on the box's host cores, as S/t and with the same bus factor as `value`
+             (a reported baseline, not a target)
 
 torch is used for device memory, streams, events and the gloo rendezvous only.
 """
@@ -183,6 +186,7 @@ def main():
 
     # correctness spot check on the first elements (all-reduce): gather every rank's head over gloo
     verified = None
+    heads = None
     if args.coll == "allreduce" and not args.in_place and args.dtype == "fp32":
         import oracle as orc
         head = sendbuf[:65536].float().cpu().numpy()
@@ -214,12 +218,29 @@ def main():
         link_bytes = (n - 1) * S
     busbw = algbw * factor if n > 1 else algbw
 
+    per_gpu = (n + ndev - 1) // ndev
+    traffic_source = None
     if n == 1:
         bound, peak = "hbm", HBM_PEAK_GBPS
         alg_bytes = 2.0 * S                            # read the bucket once, write it once
+        bound_note = "one rank: device copy, 2*S bytes per launch"
+    elif per_gpu > 1:
+        # Loop-back: the ranks of this run share GPUs, no byte crosses a link, HBM is the bound.  Bytes the design moves
+        # through HBM per rank and launch: input read and output written once, every link byte written into a window
+        # and read back once per phase (all-reduce: two phases; one when the gather phase is written directly).
+        bound, peak = "hbm", HBM_PEAK_GBPS
+        if args.coll == "allreduce":
+            per_rank = 2.0 * S + (2.0 if reg_handle else 4.0) * (n - 1) / n * S
+        elif args.coll in ("broadcast", "reduce"):
+            per_rank = 2.0 * S + 2.0 * (n - 1) / n * S      # averaged over ranks: the root's n-1 copies, each written and read
+        else:
+            per_rank = (n + 1.0) * S + 2.0 * (n - 1) * S     # (n+1)*S floor plus window write + read of n-1 blocks
+        alg_bytes = per_rank * per_gpu
+        bound_note = f"{per_gpu} ranks share each GPU: HBM bytes of the design per GPU and launch, no xGMI traffic"
     else:
         bound, peak = "xgmi", (n - 1) * XGMI_LINK_GBPS
         alg_bytes = link_bytes                         # bytes that leave each GPU per launch
+        bound_note = f"one rank per GPU: bytes leaving each GPU per launch over {n - 1} links"
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -227,6 +248,9 @@ def main():
         try:
             with open(tfile) as f:
                 traffic = json.load(f).get(f"{args.coll}_{args.dtype}_{S}_n{n}")
+            if traffic is not None:
+                traffic_source = ("profiles/traffic.json: rocprofv3 --pmc passes of this command, committed with the "
+                                  "profile they came from; not re-measured in this run")
         except (OSError, ValueError):
             traffic = None
 
@@ -245,31 +269,46 @@ def main():
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,
         "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes, "bound_note": bound_note},
     }
 
-    if n == 1 and rank == 0 and not args.no_cpu_baseline and args.coll == "allreduce" and args.dtype == "fp32":
+    if rank == 0 and not args.no_cpu_baseline and args.coll == "allreduce" and args.dtype == "fp32":
         import oracle as orc
-        host_in = sendbuf.cpu().numpy()
-        host_out = np.empty_like(host_in)
-        orc.omp_sum_f32([host_in], host_out)               # page in
+        # the n host buckets: rank 0 regenerates every rank's bucket from its seed on its own GPU (same generator,
+        # same device model, same values) and keeps host copies; the first 65536 elements are compared with what the
+        # ranks themselves hold
+        hosts = []
+        same = True
+        for r in range(n):
+            if r == 0:
+                hosts.append(sendbuf.cpu().numpy())
+            else:
+                g2 = torch.Generator(device="cuda")
+                g2.manual_seed(0x5EED0000 + r)
+                t = torch.rand(count, device="cuda", generator=g2, dtype=torch.float32) * 2 - 1
+                hosts.append(t.cpu().numpy())
+                del t
+            if heads is not None:
+                same = same and bool(np.array_equal(hosts[r][:65536], heads[r]))
+        host_out = np.empty_like(hosts[0])
+        orc.omp_sum_f32(hosts, host_out)                   # page in
         reps, t_cpu = 0, 0.0
         while t_cpu < args.cpu_seconds and reps < 50:
             c0 = time.perf_counter()
-            orc.omp_sum_f32([host_in], host_out)
+            orc.omp_sum_f32(hosts, host_out)
             t_cpu += time.perf_counter() - c0
             reps += 1
-        cpu_gbps = S * reps / t_cpu / 1e9
-        # the same fold over 8 host buckets of 1/8 the size (what an 8-rank reduce costs per output byte)
-        parts = [host_in[i * (count // 8):(i + 1) * (count // 8)] for i in range(8)]
-        c0 = time.perf_counter()
-        orc.omp_sum_f32(parts, host_out[:count // 8])
-        c8 = time.perf_counter() - c0
-        line["cpu_baseline"] = {"value": round(cpu_gbps, 3), "unit": "GB/s", "cores": orc.omp_threads(), "kind": "port",
-                                "sample": f"{reps} passes of the OpenMP element-wise sum (oracle/oracle.c) over the same "
-                                          f"{S} B fp32 bucket, 1 rank => S/t of a host copy; 8-way sum of 8 x {S // 8} B "
-                                          f"buckets ran at {round(S / 8 / c8 / 1e9, 3)} GB/s of output",
+        cpu_algbw = S * reps / t_cpu / 1e9
+        cpu_value = cpu_algbw * factor if n > 1 else cpu_algbw
+        line["cpu_baseline"] = {"value": round(cpu_value, 3), "unit": "GB/s", "cores": orc.omp_threads(), "kind": "port",
+                                "algbw_GBps": round(cpu_algbw, 3), "bus_factor": factor if n > 1 else None,
+                                "sample": f"{reps} passes of the OpenMP element-wise sum (oracle/oracle.c, "
+                                          f"'#pragma omp parallel for simd') of {n} host bucket(s) of {S} B fp32 into one "
+                                          f"output: reads {n}*S, writes S per pass; value = S/t"
+                                          + (f" x 2(n-1)/n = {factor:.3f} (the bus factor of `value`)" if n > 1
+                                             else " (one rank: a host copy, as the device path is a device copy)"),
+                                "buckets_match_ranks": same if heads is not None else None,
                                 "host_cpus": os.cpu_count()}
 
     if reg_handle:

@@ -21,14 +21,26 @@
 extern "C" {
 #endif
 
-/* Reports the NCCL API level this library tracks (reference: RCCL 2.21.5). */
-#define RCCL_AMD_NCCL_VERSION_CODE 22105
+/* The NCCL API level this library tracks (reference: RCCL 2.21.5; nccl.h.in:15-21). */
+#define NCCL_MAJOR 2
+#define NCCL_MINOR 21
+#define NCCL_PATCH 5
+#define NCCL_SUFFIX ""
+#define NCCL_VERSION_CODE 22105
+#define NCCL_VERSION(X,Y,Z) (((X) <= 2 && (Y) <= 8) ? (X) * 1000 + (Y) * 100 + (Z) : (X) * 10000 + (Y) * 100 + (Z))
+#define RCCL_AMD_NCCL_VERSION_CODE NCCL_VERSION_CODE
+/* feature macros of the reference header (nccl.h.in:23-26) */
+#define RCCL_BFLOAT16 1
+#define RCCL_FLOAT8 1
+#define RCCL_GATHER_SCATTER 1
+#define RCCL_ALLTOALLV 1
 
 /* Same declaration as <hip/hip_runtime_api.h>; repeating an identical typedef is legal in C11 and C++. */
 typedef struct ihipStream_t* hipStream_t;
 
 /* nccl.h.in:36-42 */
 typedef struct ncclComm* ncclComm_t;
+#define NCCL_COMM_NULL NULL
 #define NCCL_UNIQUE_ID_BYTES 128
 typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
 
@@ -48,6 +60,7 @@ typedef enum {
 /* nccl.h.in:63-99 */
 #define NCCL_CONFIG_UNDEF_INT INT_MIN
 #define NCCL_CONFIG_UNDEF_PTR NULL
+#define NCCL_SPLIT_NOCOLOR -1
 typedef struct ncclConfig_v21700 {
   size_t size;
   unsigned int magic;
@@ -101,12 +114,15 @@ ncclResult_t ncclCommAbort(ncclComm_t comm);                                 /* 
 ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);               /* nccl.h.in:295 */
 ncclResult_t ncclCommCuDevice(const ncclComm_t comm, int* device);           /* nccl.h.in:306 */
 ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);             /* nccl.h.in:317 */
+/* Device memory of the type peers may write into (fine-grained, not cached by the owner's kernels). */
 ncclResult_t ncclMemAlloc(void** ptr, size_t size);                          /* nccl.h.in:105 */
 ncclResult_t ncclMemFree(void* ptr);                                         /* nccl.h.in:108 */
 /* Registers a device buffer with the communicator; local call, reference-counted per allocation
  * (src/register.cc:106-160).  An all-reduce whose recvbuff lies in a registered allocation on a rank
  * lets the other ranks write their finished pieces straight into it instead of through the FIFO; so does an
- * all-gather of at least 4 MiB per rank.  Allocations of 2 GiB and more are registered locally only. */
+ * all-gather of at least 4 MiB per rank.  Peers write only into fine-grained device memory (ncclMemAlloc, or
+ * hipExtMallocWithFlags with the uncached / fine-grained flag): a registration of ordinary hipMalloc memory, and of
+ * allocations of 2 GiB and more, stays local and its collectives keep using the FIFOs. */
 ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle);   /* nccl.h.in:324 */
 ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle);                           /* nccl.h.in:330 */
 
@@ -138,6 +154,12 @@ ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, n
 ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm,
                        hipStream_t stream);                                              /* nccl.h.in:478 */
 
+/* ---- communicator split --------------------------------------------------------------------- */
+/* Ranks that pass the same colour form a new communicator, ordered by (key, rank in `comm`); NCCL_SPLIT_NOCOLOR
+ * leaves *newcomm NULL.  Collective over `comm`: every rank must call it. */
+ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm,
+                           ncclConfig_t* config);                                        /* nccl.h.in:247 */
+
 /* ---- declared by the reference, outside this library's path ----------------- */
 /* These exist so that a program using them still links; each returns
  * ncclInvalidUsage and records a message for ncclGetLastError. */
@@ -145,8 +167,22 @@ ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatyp
                       ncclComm_t comm, hipStream_t stream);                              /* nccl.h.in:587 */
 ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,
                       hipStream_t stream);                                               /* nccl.h.in:609 */
-ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm,
-                           ncclConfig_t* config);                                        /* nccl.h.in:247 */
+ncclResult_t ncclGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, int root,
+                        ncclComm_t comm, hipStream_t stream);                            /* nccl.h.in:632 */
+ncclResult_t ncclScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, int root,
+                         ncclComm_t comm, hipStream_t stream);                           /* nccl.h.in:654 */
+ncclResult_t ncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype,
+                          ncclComm_t comm, hipStream_t stream);                          /* nccl.h.in:677 */
+ncclResult_t ncclAllToAllv(const void* sendbuff, const size_t sendcounts[], const size_t sdispls[], void* recvbuff,
+                           const size_t recvcounts[], const size_t rdispls[], ncclDataType_t datatype,
+                           ncclComm_t comm, hipStream_t stream);                         /* nccl.h.in:702 */
+typedef int mscclAlgoHandle_t;                                                           /* nccl.h.in:717 */
+ncclResult_t mscclLoadAlgo(const char* mscclAlgoFilePath, mscclAlgoHandle_t* mscclAlgoHandle, int rank);   /* nccl.h.in:729 */
+ncclResult_t mscclRunAlgo(const void* sendBuff, const size_t sendCounts[], const size_t sDisPls[], void* recvBuff,
+                          const size_t recvCounts[], const size_t rDisPls[], size_t count, ncclDataType_t dataType,
+                          int root, int peer, ncclRedOp_t op, mscclAlgoHandle_t mscclAlgoHandle, ncclComm_t comm,
+                          hipStream_t stream);                                           /* nccl.h.in:755 */
+ncclResult_t mscclUnloadAlgo(mscclAlgoHandle_t mscclAlgoHandle);                         /* nccl.h.in:776 */
 
 
 /* ---- profiling aliases ---------------------------------------------------------------------- */
@@ -183,6 +219,13 @@ ncclResult_t pncclBcast(void* buff, size_t count, ncclDataType_t datatype, int r
 ncclResult_t pncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
 ncclResult_t pncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
 ncclResult_t pncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config);
+ncclResult_t pncclGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pncclAllToAllv(const void* sendbuff, const size_t sendcounts[], const size_t sdispls[], void* recvbuff, const size_t recvcounts[], const size_t rdispls[], ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pmscclLoadAlgo(const char* mscclAlgoFilePath, mscclAlgoHandle_t* mscclAlgoHandle, int rank);
+ncclResult_t pmscclRunAlgo(const void* sendBuff, const size_t sendCounts[], const size_t sDisPls[], void* recvBuff, const size_t recvCounts[], const size_t rDisPls[], size_t count, ncclDataType_t dataType, int root, int peer, ncclRedOp_t op, mscclAlgoHandle_t mscclAlgoHandle, ncclComm_t comm, hipStream_t stream);
+ncclResult_t pmscclUnloadAlgo(mscclAlgoHandle_t mscclAlgoHandle);
 
 /* ---- extensions (no counterpart in nccl.h.in) -------------------------------- */
 

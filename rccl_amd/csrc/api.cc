@@ -100,22 +100,18 @@ RA_API ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
   return ncclSuccess;
 }
 
-RA_API ncclResult_t ncclMemAlloc(void** ptr, size_t size) {
-  if (!ptr) return ncclInvalidArgument;
-  RA_HIP(hipMalloc(ptr, size));
-  return ncclSuccess;
-}
-RA_API ncclResult_t ncclMemFree(void* ptr) {
-  RA_HIP(hipFree(ptr));
-  return ncclSuccess;
-}
+// The reference's ncclMemAlloc is a plain device allocation on this platform (src/init.cc:2891-2966: the cuMem path
+// needs multicast support, else cudaMalloc).  Here it returns fine-grained (uncached) device memory: the type a
+// registered buffer must have for peers to write into it (reg.h, memory-type rule).
+RA_API ncclResult_t ncclMemAlloc(void** ptr, size_t size) { return raMemAlloc(ptr, size); }
+RA_API ncclResult_t ncclMemFree(void* ptr) { return raMemFree(ptr); }
 
 RA_API ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle) {
   RA_CHECK(raCommCheck(comm, "ncclCommRegister"));       // src/register.cc:154-160
   return raRegRegister(comm, buff, size, handle);
 }
 RA_API ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle) {
-  RA_CHECK(raCommCheck(comm, "ncclCommRegister"));       // (sic) src/register.cc:163-164
+  RA_CHECK(raCommCheck(comm, "ncclCommDeregister"));
   return raRegDeregister(comm, handle);
 }
 RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces) {
@@ -216,6 +212,17 @@ RA_API ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype,
 RA_API ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclSend"); }
 RA_API ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclRecv"); }
 RA_API ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) { return outOfScope("ncclCommSplit"); }
+RA_API ncclResult_t ncclGather(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclGather"); }
+RA_API ncclResult_t ncclScatter(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclScatter"); }
+RA_API ncclResult_t ncclAllToAll(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) { return outOfScope("ncclAllToAll"); }
+RA_API ncclResult_t ncclAllToAllv(const void*, const size_t[], const size_t[], void*, const size_t[], const size_t[], ncclDataType_t,
+                                  ncclComm_t, hipStream_t) { return outOfScope("ncclAllToAllv"); }
+// The MSCCL entry points (src/msccl.cc): the reference routes small all-reduces through that interpreter on MI300X;
+// here the planner has its own small-message path, so there is nothing to load or run.
+RA_API ncclResult_t mscclLoadAlgo(const char*, mscclAlgoHandle_t*, int) { return outOfScope("mscclLoadAlgo"); }
+RA_API ncclResult_t mscclRunAlgo(const void*, const size_t[], const size_t[], void*, const size_t[], const size_t[], size_t,
+                                 ncclDataType_t, int, int, ncclRedOp_t, mscclAlgoHandle_t, ncclComm_t, hipStream_t) { return outOfScope("mscclRunAlgo"); }
+RA_API ncclResult_t mscclUnloadAlgo(mscclAlgoHandle_t) { return outOfScope("mscclUnloadAlgo"); }
 
 RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, size_t count, ncclDataType_t datatype,
                                       ncclRedOp_t op, hipStream_t stream) {
@@ -225,7 +232,7 @@ RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int ns
   const size_t bytes = count * raTypeSize(datatype);
   const int grid = raLocalGrid(bytes, nsrc);
   static const int devOps[] = {RA_OP_SUM, RA_OP_PROD, RA_OP_MAX, RA_OP_MIN};
-  hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, count, datatype, devOps[op], grid, stream);
+  hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, nullptr, count, datatype, devOps[op], grid, stream);
   if (e != hipSuccess) { RA_WARN("rcclAmdReduceCopy: launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
   return ncclSuccess;
 }
@@ -302,3 +309,10 @@ RA_API ncclResult_t pncclBcast(void* buff, size_t count, ncclDataType_t datatype
 RA_API ncclResult_t pncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) { return ncclSend(sendbuff, count, datatype, peer, comm, stream); }
 RA_API ncclResult_t pncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream) { return ncclRecv(recvbuff, count, datatype, peer, comm, stream); }
 RA_API ncclResult_t pncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config) { return ncclCommSplit(comm, color, key, newcomm, config); }
+RA_API ncclResult_t pncclGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) { return ncclGather(sendbuff, recvbuff, sendcount, datatype, root, comm, stream); }
+RA_API ncclResult_t pncclScatter(const void* sendbuff, void* recvbuff, size_t recvcount, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) { return ncclScatter(sendbuff, recvbuff, recvcount, datatype, root, comm, stream); }
+RA_API ncclResult_t pncclAllToAll(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream) { return ncclAllToAll(sendbuff, recvbuff, count, datatype, comm, stream); }
+RA_API ncclResult_t pncclAllToAllv(const void* sendbuff, const size_t sendcounts[], const size_t sdispls[], void* recvbuff, const size_t recvcounts[], const size_t rdispls[], ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream) { return ncclAllToAllv(sendbuff, sendcounts, sdispls, recvbuff, recvcounts, rdispls, datatype, comm, stream); }
+RA_API ncclResult_t pmscclLoadAlgo(const char* mscclAlgoFilePath, mscclAlgoHandle_t* mscclAlgoHandle, int rank) { return mscclLoadAlgo(mscclAlgoFilePath, mscclAlgoHandle, rank); }
+RA_API ncclResult_t pmscclRunAlgo(const void* sendBuff, const size_t sendCounts[], const size_t sDisPls[], void* recvBuff, const size_t recvCounts[], const size_t rDisPls[], size_t count, ncclDataType_t dataType, int root, int peer, ncclRedOp_t op, mscclAlgoHandle_t mscclAlgoHandle, ncclComm_t comm, hipStream_t stream) { return mscclRunAlgo(sendBuff, sendCounts, sDisPls, recvBuff, recvCounts, rDisPls, count, dataType, root, peer, op, mscclAlgoHandle, comm, stream); }
+RA_API ncclResult_t pmscclUnloadAlgo(mscclAlgoHandle_t mscclAlgoHandle) { return mscclUnloadAlgo(mscclAlgoHandle); }

@@ -67,8 +67,20 @@ void setTimeouts(int fd) {
 
 // Service thread of one id: admit nRanks connections, then serve gather rounds until a
 // rank hangs up.
+void serveBody(int lfd, uint64_t nonce, std::vector<int>& fds);
+
+// Runs detached: nothing may escape it (an exception leaving a detached thread ends the whole process).
 void serve(int lfd, uint64_t nonce) {
   std::vector<int> fds;
+  try {
+    serveBody(lfd, nonce, fds);
+  } catch (...) {
+    RA_WARN("bootstrap: the rendezvous service of one ncclUniqueId stopped on an exception");
+  }
+  for (int fd : fds) if (fd >= 0) ::close(fd);
+}
+
+void serveBody(int lfd, uint64_t nonce, std::vector<int>& fds) {
   int nRanks = -1, joined = 0;
   struct timeval tv; tv.tv_sec = 3600; tv.tv_usec = 0;   // an id nobody uses is dropped after an hour
   setsockopt(lfd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
@@ -100,14 +112,14 @@ void serve(int lfd, uint64_t nonce) {
       ok = recvAll(fds[(size_t)r], &l, sizeof l);
       setTimeouts(fds[(size_t)r]);
       if (!ok) break;
+      // the length is checked before anything is sized by it: a bogus value ends the service, it does not throw
+      if (l > (64u << 20) || (r > 0 && l != len)) { ok = false; break; }
       if (r == 0) { len = l; buf.resize((size_t)len * (size_t)nRanks); }
-      if (l != len || len > (64u << 20)) { ok = false; break; }
       ok = len == 0 || recvAll(fds[(size_t)r], buf.data() + (size_t)r * len, (size_t)len);
     }
     for (int r = 0; r < nRanks && ok; r++)
       ok = sendAll(fds[(size_t)r], &len, sizeof len) && (len == 0 || sendAll(fds[(size_t)r], buf.data(), buf.size()));
   }
-  for (int fd : fds) if (fd >= 0) ::close(fd);
 }
 
 }  // namespace

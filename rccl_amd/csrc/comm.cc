@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <map>
+#include <thread>
 
 #include "debug.h"
 #include "net.h"
@@ -127,7 +128,6 @@ uint64_t busIdOf(int device) {
 }
 
 ncclResult_t allocWindow(ncclComm* c) {
-  makeLayout(c);
   if (c->nRanks == 1) return ncclSuccess;
   const char* kind = getenv("RCCL_AMD_WINDOW_MEM");
   void* p = nullptr;
@@ -209,6 +209,24 @@ ncclResult_t buildDevComm(ncclComm* c) {
   RA_HIP(hipMemcpy(c->devComm, &h, sizeof h, hipMemcpyHostToDevice));
   RA_HIP(hipDeviceSynchronize());
   return ncclSuccess;
+}
+
+// One line per peer about the link that joins the two GPUs (the reference builds its topology from the same
+// facts: xGMI links of one hop become <xgmi> edges, src/graph/xml.cc:780-791).  The all-pairs schedule assumes a
+// direct xGMI link to every peer; anything else still works and is slower, so it is said out loud.
+void describeLink(ncclComm* c, int peerRank, int peerDev) {
+  if (peerDev == c->device) return;
+  uint32_t type = 0, hops = 0;
+  if (hipExtGetLinkTypeAndHopCount(c->device, peerDev, &type, &hops) != hipSuccess) {
+    (void)hipGetLastError();
+    RA_INFO("rank %d (device %d) -> rank %d (device %d): link type unknown", c->rank, c->device, peerRank, peerDev);
+    return;
+  }
+  // HSA_AMD_LINK_INFO_TYPE_XGMI == 4 (hsa_ext_amd.h); hipExtGetLinkTypeAndHopCount reports that enumeration
+  const bool xgmi = type == 4;
+  if (xgmi && hops == 1) RA_INFO("rank %d (device %d) -> rank %d (device %d): xGMI, 1 hop", c->rank, c->device, peerRank, peerDev);
+  else RA_WARN("rank %d (device %d) -> rank %d (device %d): link type %u, %u hop(s): not a direct xGMI link, so the "
+               "all-pairs schedule will run below its design rate on this pair", c->rank, c->device, peerRank, peerDev, type, hops);
 }
 
 ncclResult_t enablePeer(int myDev, int peerDev) {
@@ -293,6 +311,27 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
   for (int i = 0; i < ndev; i++)
     for (int j = 0; j < i; j++) shared = shared || devs[(size_t)j] == devs[(size_t)i];
   DeviceGuard guard;
+  if (ndev > 1 && raNetRequested()) {
+    // Peer-to-peer is switched off: the ranks are set up like ranks of separate processes (rendezvous, sockets,
+    // host-staged windows), one thread each because every rank's set-up waits for the others.
+    ncclUniqueId id;
+    RA_CHECK(raBootstrapCreate(&id));
+    std::vector<ncclResult_t> results((size_t)ndev, ncclSuccess);
+    std::vector<std::thread> th;
+    for (int i = 0; i < ndev; i++) {
+      comms[i] = nullptr;
+      th.emplace_back([&, i]() {
+        if (hipSetDevice(devs[(size_t)i]) != hipSuccess) { results[(size_t)i] = ncclUnhandledCudaError; return; }
+        results[(size_t)i] = raCommInitRank(&comms[i], ndev, id, i, nullptr);
+      });
+    }
+    for (auto& t : th) t.join();
+    ncclResult_t res = ncclSuccess;
+    for (ncclResult_t r : results) if (r != ncclSuccess && res == ncclSuccess) res = r;
+    if (res != ncclSuccess)
+      for (int i = 0; i < ndev; i++) if (comms[i]) { (void)raCommDestroy(comms[i], true); comms[i] = nullptr; }
+    return res;
+  }
   auto clique = std::make_shared<RaClique>();
   clique->nRanks = ndev;
   clique->window.assign((size_t)ndev, nullptr);
@@ -307,6 +346,7 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
     readTunables(c);
     setLLGrid(c, shared);
     if (hipSetDevice(c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
+    makeLayout(c);
     res = allocWindow(c);
     clique->window[(size_t)i] = c->window;
     if (res == ncclSuccess) res = raRegInit(c, regKey);
@@ -363,6 +403,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
   ncclResult_t res = ncclSuccess;
   std::vector<PeerInfo> all((size_t)nranks);
   PeerInfo me;
+  bool windowOwned = false;      // the clique has taken the window over (it frees it when the last sibling leaves)
   const uint64_t key = raBootstrapKey(id);
   do {
     if (hipGetDevice(&c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
@@ -387,7 +428,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       res = c->boot.barrier();
       break;
     }
-    if ((res = allocWindow(c)) != ncclSuccess) break;
+    makeLayout(c);
     if (c->lay.totalBytes >= (1ull << 31)) {
       // hipIpcOpenMemHandle did not return for allocations of 2 GiB and more when tried (ROCm 7.2): refuse rather than hang
       RA_WARN("the receive window would be %zu MiB; windows shared between processes must stay below 2 GiB "
@@ -395,6 +436,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       res = ncclInvalidUsage;
       break;
     }
+    if ((res = allocWindow(c)) != ncclSuccess) break;
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
     me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash(); me.busId = busIdOf(c->device);
@@ -418,6 +460,7 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       c->clique->window[(size_t)rank] = c->window;
       c->clique->device[(size_t)rank] = c->device;
       c->clique->joined++;
+      windowOwned = true;
     }
     for (int p = 0; p < nranks && res == ncclSuccess; p++) {
       const PeerInfo& pi = all[(size_t)p];
@@ -428,6 +471,8 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
         res = ncclInvalidUsage; break;
       }
       if (p == rank) { c->peerWin[p] = c->window; continue; }
+      if (pi.pid != me.pid) c->peersElsewhere = true;
+      if (pi.busId != me.busId) describeLink(c, p, pi.device);
       if (pi.pid == me.pid) {
         c->peerWin[p] = (char*)(uintptr_t)pi.windowPtr;
         res = enablePeer(c->device, pi.device);
@@ -454,9 +499,17 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
   if (res != ncclSuccess) {
     RA_WARN("ncclCommInitRank failed for rank %d of %d", rank, nranks);
     c->boot.close();
-    raNetShutdown(c);
+    raNetShutdown(c, false);
     for (int p = 0; p < nranks; p++) if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
     freeLocal(c);
+    if (windowOwned) {
+      std::lock_guard<std::mutex> g(gCliqueMutex);
+      c->clique->left++;
+      if (c->clique->left >= c->clique->joined) gCliques.erase(c->clique->key);
+    } else if (c->window && !c->net) {
+      (void)hipFree(c->window);      // allocated, never handed to a clique
+    }
+    c->clique.reset();
     c->magic = 0;
     delete c;
     return res;
@@ -474,10 +527,12 @@ ncclResult_t raCommDestroy(ncclComm_t c, bool abort) {
   if (c->haveLast) (void)hipStreamSynchronize(c->lastStream);
   (void)hipGetLastError();
   if (c->multiProcess) {
-    // Peers may still be posting credits into this window: leave together.
-    if (!abort) (void)c->boot.barrier();
+    // Peers in other processes may still be posting credits into this window: leave together.  Ranks of one process
+    // need no such wait (their clique keeps every window alive until the last of them has left), so one thread may
+    // destroy its communicators one after the other, as the reference allows.
+    if (!abort && c->peersElsewhere) (void)c->boot.barrier();
     c->boot.close();
-    raNetShutdown(c);
+    raNetShutdown(c, !abort);
     for (int p = 0; p < c->nRanks; p++)
       if (c->peerIsIpc[p]) (void)hipIpcCloseMemHandle(c->peerWin[p]);
   }

@@ -68,6 +68,7 @@ struct ncclComm {
   std::shared_ptr<RaClique> clique;
   RaBootstrap boot;
   bool multiProcess = false;
+  bool peersElsewhere = false;       // some rank of this communicator lives in another process
   RaNet* net = nullptr;              // host-staged TCP transport state, when selected
 
   // launch ordering between user streams

@@ -124,6 +124,8 @@ struct RaWork {
   size_t chunkElems;   // elements one owner handles per round (a multiple of 16 bytes)
   size_t lastChunkElems;  // same, for the final partial round
   uint64_t opArg;      // PreMulSum scalar bits / SumPostDiv divisor
+  const void* opArgPtr;  // non-null: the PreMulSum scalar lives in device memory and is read when the kernel runs
+                         // (ncclScalarDevice; the reference's scalarArgIsPtr, src/enqueue.cc:1962-2057)
   uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
   int root;            // broadcast / reduce
   uint64_t regWord;    // announce word for recv (0: not registered)

@@ -150,12 +150,8 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   if (reduces) RA_CHECK(translateOp(c, a.op, a.dtype, &devOp, &arg, &argPtr));
   DeviceGuard guard;
   guard.set(c->device);
-  if (argPtr) {
-    // Device-resident scalar (ncclScalarDevice): fetched in stream order, before the kernel.
-    RA_HIP(hipMemcpyAsync(&c->hostFlags[8], argPtr, es, hipMemcpyDeviceToHost, a.stream));
-    RA_HIP(hipStreamSynchronize(a.stream));
-    arg = 0; memcpy(&arg, &c->hostFlags[8], es);
-  }
+  // A device-resident scalar (ncclScalarDevice) travels as a pointer: the kernel reads it when it runs, so nothing
+  // here waits for the stream and a captured launch replays with the scalar's value at that time.
   // Operations of one communicator run in issue order even when the streams differ.
   if (c->haveLast && c->lastStream != a.stream) {
     RA_HIP(hipEventRecord(c->orderEvent, c->lastStream));
@@ -171,8 +167,8 @@ ncclResult_t launchOne(const RaCollArgs& a) {
     const void* srcs[1] = {a.send};
     const size_t bytes = a.count * es;
     int grid = raLocalGrid(bytes, 1);
-    hipError_t e = scale ? raLaunchLocal(a.recv, srcs, 1, 0, false, arg, a.count, a.dtype, RA_OP_PREMULSUM, grid, a.stream)
-                         : raLaunchLocal(a.recv, srcs, 1, -1, false, 0, bytes, ncclInt8, RA_OP_SUM, grid, a.stream);
+    hipError_t e = scale ? raLaunchLocal(a.recv, srcs, 1, 0, false, arg, argPtr, a.count, a.dtype, RA_OP_PREMULSUM, grid, a.stream)
+                         : raLaunchLocal(a.recv, srcs, 1, -1, false, 0, nullptr, bytes, ncclInt8, RA_OP_SUM, grid, a.stream);
     if (e != hipSuccess) { RA_WARN("local kernel launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
     return ncclSuccess;
   }
@@ -183,7 +179,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   memset(&w, 0, sizeof w);
   w.coll = a.coll; w.algo = p.algo; w.nChannels = p.nChannels; w.elemSize = (int)es;
   w.send = (const char*)a.send; w.recv = (char*)a.recv; w.count = a.count;
-  w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg;
+  w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg; w.opArgPtr = argPtr;
   w.stepBytes = (uint32_t)(p.chunkElems * es);
   w.root = a.root;
   if (a.coll == RA_COLL_ALLREDUCE && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net)

@@ -48,8 +48,8 @@ static hipError_t llOp(const RaDevComm* comm, const RaWork& w, hipStream_t s) {
   return hipGetLastError();
 }
 template <int OP>
-static hipError_t localOp(const RcArgs& a, size_t nelem, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(RA_LOCAL_THREADS), 0, s, a, nelem);
+static hipError_t localOp(const RcArgs& a, size_t nelem, const void* opArgPtr, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(RA_LOCAL_THREADS), 0, s, a, nelem, opArgPtr);
   return hipGetLastError();
 }
 
@@ -82,15 +82,15 @@ hipError_t RA_CAT(raLaunchLLDt, RA_DTYPE)(const RaDevComm* comm, const RaWork& w
   }
 }
 
-hipError_t RA_CAT(raLaunchLocalDt, RA_DTYPE)(const RcArgs& a, size_t nelem, int op, int grid, hipStream_t s) {
+hipError_t RA_CAT(raLaunchLocalDt, RA_DTYPE)(const RcArgs& a, size_t nelem, const void* opArgPtr, int op, int grid, hipStream_t s) {
   switch (op) {
-    case RA_OP_SUM: return localOp<RA_OP_SUM>(a, nelem, grid, s);
-    case RA_OP_PROD: return localOp<RA_OP_PROD>(a, nelem, grid, s);
-    case RA_OP_MAX: return localOp<RA_OP_MAX>(a, nelem, grid, s);
-    case RA_OP_MIN: return localOp<RA_OP_MIN>(a, nelem, grid, s);
-    case RA_OP_PREMULSUM: return localOp<RA_OP_PREMULSUM>(a, nelem, grid, s);
+    case RA_OP_SUM: return localOp<RA_OP_SUM>(a, nelem, opArgPtr, grid, s);
+    case RA_OP_PROD: return localOp<RA_OP_PROD>(a, nelem, opArgPtr, grid, s);
+    case RA_OP_MAX: return localOp<RA_OP_MAX>(a, nelem, opArgPtr, grid, s);
+    case RA_OP_MIN: return localOp<RA_OP_MIN>(a, nelem, opArgPtr, grid, s);
+    case RA_OP_PREMULSUM: return localOp<RA_OP_PREMULSUM>(a, nelem, opArgPtr, grid, s);
 #if RA_IS_INT
-    case RA_OP_SUMPOSTDIV: return localOp<RA_OP_SUMPOSTDIV>(a, nelem, grid, s);
+    case RA_OP_SUMPOSTDIV: return localOp<RA_OP_SUMPOSTDIV>(a, nelem, opArgPtr, grid, s);
 #endif
     default: return hipErrorInvalidValue;
   }

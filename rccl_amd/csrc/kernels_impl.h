@@ -516,10 +516,20 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
   }
 }
 
+// A pre-multiply scalar that lives in device memory (ncclScalarDevice) is read when the kernel runs, never on the
+// host at enqueue time: a captured launch replays with whatever the scalar holds then (the reference dereferences
+// it on the device as well, src/device/reduce_kernel.h:364-457 with scalarArgIsPtr).
+template <typename T> __device__ __forceinline__ uint64_t loadScalarArg(const void* p) {
+  union { uint64_t u; T t; } x; x.u = 0;
+  x.t = *(const T*)p;
+  return uniform64(x.u);
+}
+
 // ------------------------------------------------------------------ local kernels
 // One rank (src/device/onerank.cu) and the exported N-source reduce-copy.
 template <typename T, int OP>
-__global__ __launch_bounds__(1024) void raLocalKernel(RcArgs a, size_t nelem) {
+__global__ __launch_bounds__(1024) void raLocalKernel(RcArgs a, size_t nelem, const void* opArgPtr) {
+  if (OP == RA_OP_PREMULSUM && opArgPtr) a.opArg = loadScalarArg<T>(opArgPtr);
   reduceCopy<T, OP>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
 }
 
@@ -1373,6 +1383,7 @@ __device__ __forceinline__ void llFold(const RaDevComm* comm, const RaWork& w, c
 template <typename T, int OP>
 __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDevComm* __restrict__ comm, RaWork w) {
   const int n = comm->nRanks, r = comm->rank;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
   uint32_t epoch = comm->llEpoch[blockIdx.x] + 1;
   if (epoch == 0) epoch = 1;
   const int buf = (int)(epoch & 1u);
@@ -1445,6 +1456,7 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   __shared__ ChanShared sh;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
   cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
   if (w.algo == RA_ALGO_DIRECT) {
     if (w.coll == RA_COLL_ALLREDUCE) directAllReduce<T, OP>(cx, w, role);

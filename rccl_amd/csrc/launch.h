@@ -16,8 +16,9 @@ hipError_t raLaunchLL(const RaDevComm* comm, const RaWork& w, int dtype, int op,
 #define RA_LOCAL_TILE_BYTES (RA_LOCAL_THREADS * 128)
 
 // dst[i] = fold of srcs[0..nsrc-1][i] on the current device, `grid` workgroups of RA_LOCAL_THREADS threads.
+// opArgPtr (may be null): device address of the pre-multiply scalar, read by the kernel instead of opArg.
 hipError_t raLaunchLocal(void* dst, const void* const* srcs, int nsrc, int preIdx, bool post, uint64_t opArg,
-                         size_t nelem, int dtype, int op, int grid, hipStream_t s);
+                         const void* opArgPtr, size_t nelem, int dtype, int op, int grid, hipStream_t s);
 
 // Grid for a local kernel producing `outBytes` from `nsrc` sources: one tile per workgroup (a tile is
 // RA_LOCAL_THREADS x U packs with nsrc*U = 8, see reduceCopy), grid-stride beyond 64 Ki tiles.

@@ -22,6 +22,7 @@
 #include <poll.h>
 #include <sched.h>
 #include <string.h>
+#include <strings.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -74,6 +75,7 @@ struct RaNet {
   std::vector<uint64_t> sentTail, sentHead;   // [peer][ch][kind]
   std::thread tx, rx;
   std::atomic<bool> stop{false};
+  std::atomic<bool> draining{false};     // shutdown has begun: tx leaves after a pass that found nothing left to ship
   std::atomic<uint64_t> bytesSent{0};
 
   size_t ix(int p, int ch, int k) const { return ((size_t)p * lay.nChannels + ch) * RA_NKINDS + k; }
@@ -118,7 +120,10 @@ struct RaNet {
             }
           }
       }
-      if (!progress) sched_yield();
+      if (!progress) {
+        if (draining.load(std::memory_order_relaxed)) return;   // this rank's kernels are done and all of it is shipped
+        sched_yield();
+      }
     }
   }
 
@@ -135,7 +140,12 @@ struct RaNet {
         if (!(pf[i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
         const int p = who[i];
         MsgHeader h;
-        if (!recvAll(pf[i].fd, &h, sizeof h)) { if (!stop.load()) fail("recv"); return; }
+        // A peer that has shipped everything closes its sending side: an end of stream on a message boundary is
+        // that rank leaving in good order, not a failure (what it owed this rank has already arrived).
+        ssize_t got = ::recv(pf[i].fd, &h, sizeof h, MSG_WAITALL);
+        if (got == 0) { pf[i].fd = -1; continue; }
+        if (got < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+        if (got != (ssize_t)sizeof h) { if (!stop.load()) fail("recv"); return; }
         if ((int)h.ch >= lay.nChannels || h.kind >= RA_NKINDS || h.nbytes > lay.slotBytes) { errno = EPROTO; fail("message check"); return; }
         if (h.type == MSG_DATA) {
           const int slot = (int)((h.step - 1) % (uint64_t)lay.nSlots);
@@ -153,11 +163,26 @@ struct RaNet {
 };
 
 bool raNetRequested() {
-  // NCCL_P2P_DISABLE=1 turns the peer-to-peer transport off (src/graph/paths.cc:287-291); this
-  // library has no shared-memory transport, so the next choice is the socket transport, exactly
-  // what NCCL_SHM_DISABLE=1 NCCL_NET=Socket makes of the reference.
+  // NCCL_P2P_DISABLE=1 turns the peer-to-peer transport off (src/graph/paths.cc:287-291).  The reference would try
+  // shared memory next (transport order P2P, SHM, NET: src/transport.cc:14-53) unless NCCL_SHM_DISABLE=1
+  // (src/transport/shm.cc:40-54); this library has no shared-memory transport, so with peer-to-peer off the socket
+  // transport is what remains, whatever NCCL_SHM_DISABLE says.  NCCL_NET (src/init.cc:2150) can only name that one,
+  // and a single node's ranks always meet over the loopback interface (NCCL_SOCKET_IFNAME, src/misc/socket.cc:331-357).
   const char* e = getenv("NCCL_P2P_DISABLE");
-  return e && atoi(e) != 0;
+  const bool on = e && atoi(e) != 0;
+  static std::atomic<bool> said{false};
+  if (on && !said.exchange(true)) {
+    const char* shm = getenv("NCCL_SHM_DISABLE");
+    const char* net = getenv("NCCL_NET");
+    const char* ifn = getenv("NCCL_SOCKET_IFNAME");
+    if (!(shm && atoi(shm) != 0))
+      RA_INFO("NCCL_P2P_DISABLE=1 without NCCL_SHM_DISABLE=1: there is no shared-memory transport here, the socket transport is used");
+    if (net && *net && strcasecmp(net, "Socket"))
+      RA_WARN("NCCL_NET=%s: the only network transport here is the built-in one (\"Socket\"); using it", net);
+    if (ifn && *ifn && strcmp(ifn, "lo") && strcmp(ifn, "=lo"))
+      RA_INFO("NCCL_SOCKET_IFNAME=%s: ranks of one node are connected over the loopback interface", ifn);
+  }
+  return on;
 }
 
 ncclResult_t raNetSetup(ncclComm* c) {
@@ -228,12 +253,17 @@ ncclResult_t raNetSetup(ncclComm* c) {
   return ncclSuccess;
 }
 
-void raNetShutdown(ncclComm* c) {
+void raNetShutdown(ncclComm* c, bool drain) {
   RaNet* N = c->net;
   if (!N) return;
-  N->stop.store(true);
-  for (int fd : N->sock) if (fd >= 0) ::shutdown(fd, SHUT_RDWR);
+  // The caller has waited for this rank's kernels.  What they published may still sit in the shadows: let the tx
+  // thread ship it (it leaves after a pass with nothing to do), then close the sending side so that every peer
+  // sees an orderly end of stream, and only then stop receiving.
+  if (drain) N->draining.store(true); else N->stop.store(true);
   if (N->tx.joinable()) N->tx.join();
+  for (int fd : N->sock) if (fd >= 0) ::shutdown(fd, SHUT_WR);
+  N->stop.store(true);
+  for (int fd : N->sock) if (fd >= 0) ::shutdown(fd, SHUT_RD);
   if (N->rx.joinable()) N->rx.join();
   for (int fd : N->sock) if (fd >= 0) ::close(fd);
   if (N->real) (void)hipHostFree(N->real);

@@ -7,4 +7,5 @@ bool raNetRequested();
 // Allocates the pinned host windows, fills c->peerWin with their device addresses, connects the
 // socket mesh over the bootstrap and starts the proxy threads.  c->lay must be final.
 ncclResult_t raNetSetup(ncclComm* c);
-void raNetShutdown(ncclComm* c);
+// drain: ship what this rank's (finished) kernels still have pending before the sockets close; false on abort / failed set-up.
+void raNetShutdown(ncclComm* c, bool drain);

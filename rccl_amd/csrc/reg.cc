@@ -3,7 +3,10 @@
 
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -11,6 +14,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -162,6 +166,64 @@ void refreshPeer(ncclComm* c, RaRegState* s, int p) {
 
 }  // namespace
 
+// ----- peer-writable memory -------------------------------------------------------------------
+namespace {
+std::mutex gMemMutex;
+std::map<uintptr_t, size_t> gMemAllocs;      // allocations made by ncclMemAlloc in this process
+}  // namespace
+
+ncclResult_t raMemAlloc(void** ptr, size_t size) {
+  if (!ptr) { RA_WARN("ncclMemAlloc: ptr is NULL"); return ncclInvalidArgument; }
+  *ptr = nullptr;
+  if (size == 0) return ncclSuccess;
+  // Same preference as for the library's own windows (and the reference's peer-written buffers, src/include/alloc.h:34-36).
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, size, hipDeviceMallocUncached);
+  if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, size, hipDeviceMallocFinegrained); }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    RA_WARN("ncclMemAlloc: cannot allocate %zu bytes of fine-grained device memory: %s", size, hipGetErrorString(e));
+    return ncclUnhandledCudaError;
+  }
+  {
+    std::lock_guard<std::mutex> g(gMemMutex);
+    gMemAllocs[(uintptr_t)p] = size;
+  }
+  *ptr = p;
+  return ncclSuccess;
+}
+
+ncclResult_t raMemFree(void* ptr) {
+  if (!ptr) return ncclSuccess;
+  {
+    std::lock_guard<std::mutex> g(gMemMutex);
+    gMemAllocs.erase((uintptr_t)ptr);
+  }
+  RA_HIP(hipFree(ptr));
+  return ncclSuccess;
+}
+
+bool raMemPeerWritable(const void* base, size_t size) {
+  const uintptr_t a = (uintptr_t)base;
+  {
+    std::lock_guard<std::mutex> g(gMemMutex);
+    auto it = gMemAllocs.upper_bound(a);
+    if (it != gMemAllocs.begin()) {
+      --it;
+      if (a >= it->first && a + size <= it->first + it->second) return true;
+    }
+  }
+  // Not ours: ask the runtime which pool the allocation came from (hipExtMallocWithFlags with the uncached or
+  // fine-grained flag allocates from the device's fine-grained pool).
+  hsa_amd_pointer_info_t info;
+  memset(&info, 0, sizeof info);
+  info.size = sizeof info;
+  if (hsa_amd_pointer_info(base, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
+  if (info.type != HSA_EXT_POINTER_TYPE_HSA) return false;
+  return (info.global_flags & (HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_FINE_GRAINED |
+                               HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_EXTENDED_SCOPE_FINE_GRAINED)) != 0;
+}
+
 uint64_t raRegLocalKey() {
   static std::atomic<uint32_t> counter{0};
   struct timespec ts;
@@ -233,7 +295,14 @@ ncclResult_t raRegRegister(ncclComm* c, void* buff, size_t size, void** handle) 
   }
   RegLocal* r = new RegLocal;
   r->addr = (uintptr_t)base; r->size = asize; r->refs = 1; r->slot = -1; r->serial = 0;
-  if (s->mine) {
+  // Published (so that peers write into it) only when it is memory a peer may write: see reg.h.  RCCL_AMD_REG_COARSE=1
+  // lifts the rule for experiments.
+  static const bool anyType = []() { const char* e = getenv("RCCL_AMD_REG_COARSE"); return e && atoi(e) != 0; }();
+  const bool writable = anyType || raMemPeerWritable((const void*)base, asize);
+  if (s->mine && !writable)
+    RA_INFO("ncclCommRegister: %p lies in ordinary (coarse-grained) device memory: registered locally only, collectives on "
+            "it keep using the FIFOs (allocate with ncclMemAlloc for direct writes)", buff);
+  if (s->mine && writable) {
     int slot = -1;
     for (int i = 0; i < RA_MAX_REGS && slot < 0; i++)
       if (s->mine->e[i].serial == 0) slot = i;

@@ -18,16 +18,64 @@ import numpy as np
 COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE = 0, 1, 2, 3, 4
 
 
-def _sweep(torch):
-    """Push whatever earlier kernels and copies left in this GPU's caches out of them (512 MiB of other traffic).
-    With several processes on one GPU, older copies of 128-byte lines were seen to resurface after a newer write on
-    some boxes (tools/torch_fill_copy_probe.py shows it without this library); the protocol under test does not depend
-    on cache residue, so the bed removes it after preparing buffers and before launching."""
-    sweep = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
-    sweep.fill_(1)
-    int(sweep.sum().item())
-    del sweep
-    torch.cuda.synchronize()
+class _DevBuf:
+    """A raw device allocation filled and read with hipMemcpy (no torch tensor): `fine` = ncclMemAlloc (fine-grained,
+    what a peer may write into), else plain hipMalloc (coarse-grained)."""
+
+    _hip = None
+
+    def __init__(self, ra, nbytes, fine, fill=None, image=None):
+        import ctypes
+        if _DevBuf._hip is None:
+            _DevBuf._hip = ctypes.CDLL("libamdhip64.so")
+        self.ct, self.ra, self.n, self.fine = ctypes, ra, int(nbytes), fine
+        if fine:
+            self.p = ra.mem_alloc(max(self.n, 16))
+        else:
+            q = ctypes.c_void_p()
+            rc = self._hip.hipMalloc(ctypes.byref(q), ctypes.c_size_t(max(self.n, 16)))
+            if rc != 0:
+                raise RuntimeError(f"hipMalloc failed with {rc}")
+            self.p = q.value
+        if fill is not None:
+            self.fill(fill)
+        if image is not None:
+            self.write(0, image)
+
+    def data_ptr(self):
+        return self.p
+
+    def numel(self):
+        return self.n
+
+    def fill(self, value):
+        rc = self._hip.hipMemset(self.ct.c_void_p(self.p), self.ct.c_int(value), self.ct.c_size_t(self.n))
+        rc = rc or self._hip.hipDeviceSynchronize()
+        if rc != 0:
+            raise RuntimeError(f"hipMemset failed with {rc}")
+
+    def write(self, off, image):
+        image = np.ascontiguousarray(image).view(np.uint8).ravel()
+        rc = self._hip.hipMemcpy(self.ct.c_void_p(self.p + off), self.ct.c_void_p(image.ctypes.data),
+                                 self.ct.c_size_t(image.size), self.ct.c_int(1))
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy to the device failed with {rc}")
+
+    def read(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        rc = self._hip.hipMemcpy(self.ct.c_void_p(out.ctypes.data), self.ct.c_void_p(self.p), self.ct.c_size_t(self.n),
+                                 self.ct.c_int(2))
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy from the device failed with {rc}")
+        return out
+
+    def free(self):
+        if self.p:
+            if self.fine:
+                self.ra.mem_free(self.p)
+            else:
+                self._hip.hipFree(self.ct.c_void_p(self.p))
+            self.p = 0
 
 
 def _child(rank, nranks, device, conn, env):
@@ -77,16 +125,12 @@ def _child(rank, nranks, device, conn, env):
                 host_in = np.frombuffer(a["input"], dtype=np.uint8)
 
                 def upload(image):
-                    """One host-to-device copy per buffer, read back before use.  (A device-side fill followed by a
-                    device copy over it was seen to leave whole cache lines of the fill value behind on some boxes
-                    when several processes share the GPU; tools/torch_fill_copy_probe.py is the stand-alone probe.)"""
-                    for attempt in range(2):
-                        t = torch.from_numpy(image).cuda()
-                        torch.cuda.synchronize()
-                        if np.array_equal(t.cpu().numpy(), image):
-                            return t
-                        print(f"testbed rank {rank}: an uploaded buffer read back differently (attempt {attempt})", flush=True)
-                    raise RuntimeError("test bed: a host-to-device upload does not read back as written")
+                    """One host-to-device copy per buffer; it must read back as written."""
+                    t = torch.from_numpy(image).cuda()
+                    torch.cuda.synchronize()
+                    if not np.array_equal(t.cpu().numpy(), image):
+                        raise RuntimeError("test bed: a host-to-device upload does not read back as written")
+                    return t
 
                 # pad = (bytes in front of sendbuff, bytes in front of recvbuff): unaligned user pointers.  Every
                 # buffer ends in a 64-byte guard that must come back untouched.
@@ -147,12 +191,18 @@ def _child(rank, nranks, device, conn, env):
                     guards = [(0, pad_r), (pad_r + a["out_bytes"], pad_r + a["out_bytes"] + GUARD)]
                 op = a["op"]
                 user_op = None
-                if a.get("premul") is not None:
+                scal_dev = scal_next = None
+                if a.get("premul") is not None and a.get("premul_device"):
+                    # the scalar lives in device memory (ncclScalarDevice): the kernel reads it when it runs
+                    scal_dev = torch.from_numpy(np.frombuffer(a["premul"], dtype=np.uint8).copy()).cuda()
+                    if a.get("premul2") is not None:
+                        scal_next = torch.from_numpy(np.frombuffer(a["premul2"], dtype=np.uint8).copy()).cuda()
+                    user_op = comm.create_premul_sum(None, a["dtype"], residence=ra.ncclScalarDevice, device_ptr=scal_dev.data_ptr())
+                    op = user_op
+                elif a.get("premul") is not None:
                     user_op = comm.create_premul_sum(a["premul"], a["dtype"])
                     op = user_op
                 torch.cuda.synchronize()
-                if not a.get("managed"):
-                    _sweep(torch)
 
                 def issue():
                     if a["coll"] == COLL_ALLREDUCE:
@@ -177,6 +227,8 @@ def _child(rank, nranks, device, conn, env):
                         g.replay()
                         stream.synchronize()
                         out_view()[pad_r:pad_r + a["out_bytes"]].fill_(0x3C)
+                        if scal_next is not None:
+                            scal_dev.copy_(scal_next)          # the second replay must pick the new scalar up
                         stream.synchronize()
                         g.replay()
                 with torch.cuda.stream(stream):
@@ -206,38 +258,44 @@ def _child(rank, nranks, device, conn, env):
                     res = res[:a["out_bytes"]]
                 conn.send(("ok", (err, res.tobytes())))
             elif cmd == "reg_prepare":
-                # args: dict(coll, dtype, count, input(bytes), in_place, register_recv): buffers that stay alive across commands
+                # args: dict(coll, dtype, count, input(bytes), in_place, register_recv, fine): buffers that stay alive across
+                # commands.  fine: the receive buffer comes from ncclMemAlloc (what peers may write into), else hipMalloc.
                 a = args
                 es = ra.TYPE_SIZE[a["dtype"]]
                 host_in = np.frombuffer(a["input"], dtype=np.uint8)
+                fine = a.get("fine", True)
                 if a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER:
-                    image = np.full(host_in.size * nranks, 0xA5, dtype=np.uint8)
+                    reg_out = _DevBuf(ra, host_in.size * nranks, fine, fill=0xA5)
                     if a["in_place"]:
-                        image[rank * host_in.size:(rank + 1) * host_in.size] = host_in
-                    reg_out = torch.from_numpy(image).cuda()
-                    reg_in = reg_out[rank * host_in.size:(rank + 1) * host_in.size] if a["in_place"] else torch.from_numpy(host_in.copy()).cuda()
+                        reg_out.write(rank * host_in.size, host_in)
+                        reg_in = reg_out.data_ptr() + rank * host_in.size
+                        reg_bufs = [reg_out]
+                    else:
+                        src = _DevBuf(ra, host_in.size, False, image=host_in)
+                        reg_in, reg_bufs = src.data_ptr(), [reg_out, src]
+                elif a["in_place"]:
+                    reg_out = _DevBuf(ra, host_in.size, fine, image=host_in)
+                    reg_in, reg_bufs = reg_out.data_ptr(), [reg_out]
                 else:
-                    reg_in = torch.from_numpy(host_in.copy()).cuda()
-                    reg_out = reg_in if a["in_place"] else torch.from_numpy(np.full(host_in.size, 0xA5, dtype=np.uint8)).cuda()
+                    src = _DevBuf(ra, host_in.size, False, image=host_in)
+                    reg_out = _DevBuf(ra, host_in.size, fine, fill=0xA5)
+                    reg_in, reg_bufs = src.data_ptr(), [reg_out, src]
                 torch.cuda.synchronize()
                 reg_handle = comm.register(reg_out.data_ptr(), reg_out.numel()) if a["register_recv"] else None
-                reg_state = (a, reg_in, reg_out, reg_handle)
+                reg_state = (a, reg_in, reg_out, reg_handle, reg_bufs)
                 conn.send(("ok", None))
             elif cmd == "reg_run":
-                a, reg_in, reg_out, reg_handle = reg_state
+                a, reg_in, reg_out, reg_handle, reg_bufs = reg_state
                 before = comm.stats()
                 gather = a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER
                 if not a["in_place"]:
-                    reg_out.fill_(0x5A)
-                    torch.cuda.synchronize()
-                    # In some process states (seen after managed allocations followed by a graph capture) a peer's
-                    # write through its IPC mapping is not coherent with lines the owner's kernels left in its L2s.
-                    _sweep(torch)
+                    reg_out.fill(0x5A)          # the owner's poison; no cache sweep follows: peers must still win
+
                 def launch():
                     if gather:
-                        comm.all_gather(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], stream)
+                        comm.all_gather(reg_in, reg_out.data_ptr(), a["count"], a["dtype"], stream)
                     else:
-                        comm.all_reduce(reg_in.data_ptr(), reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                        comm.all_reduce(reg_in, reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
 
                 if args and args.get("graph"):
                     # capture the launch on the registered buffers and replay it twice (a framework's steady state);
@@ -249,25 +307,20 @@ def _child(rank, nranks, device, conn, env):
                         g.replay()
                         stream.synchronize()
                         if not a["in_place"]:
-                            reg_out.fill_(0x3C)
-                            stream.synchronize()
-                            _sweep(torch)
+                            reg_out.fill(0x3C)
                         g.replay()
                 else:
                     launch()
                 stream.synchronize()
                 after = comm.stats()
-                conn.send(("ok", (comm.async_error(), reg_out.cpu().numpy().tobytes(),
+                conn.send(("ok", (comm.async_error(), reg_out.read().tobytes(),
                                   {k: after[k] - before[k] for k in after})))
-            elif cmd == "reg_reread":
-                # read the receive buffer again after sweeping this GPU's caches with 512 MiB of other traffic
-                a, reg_in, reg_out, reg_handle = reg_state
-                _sweep(torch)
-                conn.send(("ok", reg_out.cpu().numpy().tobytes()))
             elif cmd == "reg_release":
-                a, reg_in, reg_out, reg_handle = reg_state
+                a, reg_in, reg_out, reg_handle, reg_bufs = reg_state
                 if reg_handle is not None:
                     comm.deregister(reg_handle)
+                for bf in reg_bufs:
+                    bf.free()
                 reg_state = None
                 conn.send(("ok", None))
             elif cmd == "second_comm":
@@ -331,7 +384,6 @@ class TestBed:
             self.conns.append(parent)
             self.procs.append(p)
         self.inited = False
-        self.stale_reads = []
         self.answered = set()
 
     def _recv(self, r):
@@ -364,13 +416,14 @@ class TestBed:
         return info
 
     def run(self, coll, dtype, op, count, inputs, out_bytes, in_place=False, premul=None, iters=1, graph=False,
-            skip_ranks=(), expect_errors=False, root=0, pad=None, managed=False):
+            skip_ranks=(), expect_errors=False, root=0, pad=None, managed=False, premul_device=False, premul2=None):
         """inputs: one numpy array per rank.  Returns one uint8 array (out_bytes) per rank."""
         if not self.inited:
             self.init_comms()
         args = [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
                      out_bytes=out_bytes, in_place=in_place, premul=None if premul is None else premul[r], iters=iters,
-                     graph=graph, skip=r in skip_ranks, root=root, pad=pad, managed=managed)
+                     graph=graph, skip=r in skip_ranks, root=root, pad=pad, managed=managed, premul_device=premul_device,
+                     premul2=None if premul2 is None else premul2[r])
                 for r in range(self.nranks)]
         res = self._all("coll", args)
         if expect_errors:
@@ -380,34 +433,24 @@ class TestBed:
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
 
     def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1, coll=COLL_ALLREDUCE,
-                       want=None, graph=False):
+                       graph=False, fine=True):
         """All-reduce (or all-gather) on buffers that stay allocated (and registered on `register_ranks`, default all) across `runs`
         launches.  Returns, per run, (outputs per rank, stats deltas per rank).  `graph`: every run after the first is
-        captured into a hipGraph and replayed twice instead of being launched directly.
-
-        `want` (the expected receive buffer, same on every rank): when a rank's output differs from it only where the
-        poison written before the launch is still visible, the buffers are read a second time after this GPU's caches
-        were swept, those bytes are returned instead and the ranks are noted in `self.stale_reads`.  (On some boxes a
-        write from another process on the SAME GPU through an IPC mapping is not seen by the owner's next read while
-        an older copy of the line sits in a cache: an artefact of running several ranks on one GPU.)"""
+        captured into a hipGraph and replayed twice instead of being launched directly.  `fine`: receive buffers come
+        from ncclMemAlloc (fine-grained memory, the type peers may write into); False: ordinary hipMalloc memory, whose
+        registration must stay local.  Every out-of-place launch starts from a receive buffer the owner has just filled
+        with poison, with no cache maintenance of any kind in between."""
         if not self.inited:
             self.init_comms()
         regs = set(range(self.nranks)) if register_ranks is None else set(register_ranks)
         self._all("reg_prepare", [dict(coll=coll, dtype=dtype, op=op, count=count, input=np.ascontiguousarray(inputs[r]).tobytes(),
-                                       in_place=in_place, register_recv=r in regs) for r in range(self.nranks)])
+                                       in_place=in_place, register_recv=r in regs, fine=fine) for r in range(self.nranks)])
         results = []
         for k in range(runs):
             res = self._all("reg_run", [dict(graph=graph and k > 0)] * self.nranks)
             for r, (err, _, _) in enumerate(res):
                 assert err == 0, f"rank {r}: asynchronous error {err}"
             outs = [np.frombuffer(b, dtype=np.uint8) for _, b, _ in res]
-            if want is not None and not in_place:
-                w = np.ascontiguousarray(want).view(np.uint8).ravel()
-                stale = [r for r in range(self.nranks)
-                         if outs[r].size == w.size and (outs[r] != w).any() and (outs[r][outs[r] != w] == 0x5A).all()]
-                if stale:
-                    outs = [np.frombuffer(b, dtype=np.uint8) for b in self._all("reg_reread", [None] * self.nranks)]
-                    self.stale_reads.append(stale)
             results.append((outs, [st for _, _, st in res]))
             if in_place and coll == COLL_ALLREDUCE:
                 break          # a second in-place run would reduce the first one's output
