@@ -178,7 +178,7 @@ ncclResult_t buildDevComm(ncclComm* c) {
   RA_HIP(hipMemset(c->regTable, 0, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
   RA_HIP(hipMalloc((void**)&c->stats, 32 * sizeof(uint64_t)));
   RA_HIP(hipMemset(c->stats, 0, 32 * sizeof(uint64_t)));
-  RA_HIP(hipHostMalloc((void**)&c->hostFlags, 64, hipHostMallocMapped));
+  RA_HIP(hipHostMalloc((void**)&c->hostFlags, 64, hipHostMallocMapped | hipHostMallocCoherent));   // both sides poll it: never cached on the GPU
   memset(c->hostFlags, 0, 64);
   RA_HIP(hipHostGetDevicePointer((void**)&c->hostFlagsDev, c->hostFlags, 0));
   RA_HIP(hipEventCreateWithFlags(&c->orderEvent, hipEventDisableTiming));

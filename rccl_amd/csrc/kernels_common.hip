@@ -48,7 +48,7 @@ hipError_t raLaunchLocal(void* dst, const void* const* srcs, int nsrc, int preId
   RcArgs a;
   for (int j = 0; j < nsrc; j++) a.src[j] = (const char*)srcs[j];
   a.dst[0] = (char*)dst;
-  a.ns = nsrc; a.nd = 1; a.preIdx = preIdx; a.post = post; a.opArg = opArg;
+  a.ns = nsrc; a.nd = 1; a.nLocal = 1; a.preIdx = preIdx; a.post = post; a.opArg = opArg;
   switch (dtype) {
 #define RA_CASE(N) case N: return raLaunchLocalDt##N(a, nelem, opArgPtr, op, grid, s);
     RA_CASE(0) RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8) RA_CASE(9) RA_CASE(10) RA_CASE(11)

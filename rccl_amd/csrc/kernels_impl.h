@@ -228,12 +228,22 @@ __device__ __forceinline__ void stPack(u32x4* p, u32x4 v) { __builtin_nontempora
 // scalar 64-bit base + 32-bit per-lane byte offset
 __device__ __forceinline__ u32x4 ldAt(uint64_t base, uint32_t off) { return __builtin_nontemporal_load((gc_u32x4*)(base + off)); }
 __device__ __forceinline__ void stAt(uint64_t base, uint32_t off, u32x4 v) { __builtin_nontemporal_store(v, (g_u32x4*)(base + off)); }
-// Store into a peer's window: system-scope write-through (sc0 sc1), so the bytes are at their
-// destination once the wave's vmcnt drains and no cache write-back is needed before the flag.
-// hipcc does not count this store; every step ends with an explicit s_waitcnt vmcnt(0).
-__device__ __forceinline__ void stSysAt(uint64_t base, uint32_t off, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt" : : "v"(off), "v"(v), "s"(base) : "memory");
+// Write-through stores (system scope: sc0 sc1, streaming: nt).  The bytes are at their destination once the wave's
+// vmcnt drains, so no cache write-back is needed before a flag that announces them, and nothing stays dirty in L2.
+// Used for every byte that leaves for a peer's window and, inside the collective kernels, for the local receive
+// buffer too (an L2 with no dirty lines makes the release fence in front of every flag post cheap).
+// The bulk form goes through a buffer descriptor (base in SGPRs, 32-bit uniform and per-lane offsets): unlike
+// inline asm it is a memory instruction the compiler knows, so its s_waitcnt vmcnt(N) counts stay exact and a
+// tile's stores can still be in flight while the next tile's loads are awaited.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t bufRsrc(uint64_t base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);   // raw buffer, no range limit below 4 GiB
 }
+#define RA_AUX_WT 19   // sc0 (1) | nt (2) | sc1 (16)
+__device__ __forceinline__ void stSysAt(rsrc_t r, uint32_t soff, uint32_t off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, (int)soff, RA_AUX_WT);
+}
+// Single packs of ragged ends: hipcc does not count this store; every step ends with an explicit s_waitcnt vmcnt(0).
 __device__ __forceinline__ void stSys(u32x4* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
 }
@@ -247,7 +257,8 @@ struct RcArgs {
   char* dst[RA_MAX_SRCS];
   int ns, nd, preIdx;
   bool post;
-  uint32_t sysMask = 0;  // bit k set: dst[k] is a peer's window slot (system-scope write-through store)
+  int nLocal = 0;  // destinations [0, nLocal) are this GPU's own memory, written with plain streaming stores (0, 1, or all
+                   // of them); the rest are windows or peers' buffers, written with write-through stores
   uint64_t opArg;
 };
 
@@ -263,79 +274,134 @@ __device__ __forceinline__ const char* uniformPtr(const char* p) { return (const
 __device__ __forceinline__ char* uniformPtr(char* p) { return (char*)uniform64((uint64_t)p); }
 
 // Packs [first, npacks) in tiles of nthr*U packs; tile t starts at first + t*tileStep.
-// NS > 0: the source count is a compile-time constant and all NS*U loads are issued
-// before the first use, so one wave keeps NS*U KiB in flight.  NS == 0: any count.
-template <typename T, int OP, int NS, int U>
+//
+// LOC: how many leading destinations are local memory written with plain streaming stores (a.nLocal: 0 or 1 here; the
+// receive buffer, when it is a destination, comes first); every other destination is a window slot or a peer's buffer
+// and is written with write-through stores (it then lies within 4 GiB of a.dst[k]: a slot, or a piece of at most one slot).
+//
+// NS > 0 (source and destination counts known at compile time): software-pipelined.  All NS*U loads of a tile are
+// issued together, and the loads of the NEXT tile are issued before this tile's stores, so a wave waits for a tile's
+// loads with the previous tile's stores and the next tile's loads still in flight: store acknowledgements never stall
+// the loop and a wave keeps between NS*U and 2*NS*U 16-byte loads in flight.  Two register sets swap roles from tile
+// to tile.  The waits are the compiler's own s_waitcnt vmcnt(N); they are exact because every path through the loop
+// issues the same number of memory instructions: the counts are template arguments, the tile behind the last one is
+// "loaded" from one already-read line instead of being skipped, and the first tile is peeled so that the loop is entered
+// in its steady state.  !PIPE (the local kernels, whose workgroups mostly own a single tile): one tile at a time.
+// NS == 0: any counts, one tile at a time.
+template <typename T, int OP, int LOC, int NS, int U, int ND, bool PIPE>
 __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t firstIn, size_t tileStepIn, int tid, int nthr) {
   constexpr int NSA = NS > 0 ? NS : 1;
+  constexpr int NDA = NS > 0 ? ND : 1;
+  static_assert(NS == 0 || ND > 0, "pipelined form needs both counts");
   const size_t npacks = uniform64(npacksIn), first = uniform64(firstIn), tileStep = uniform64(tileStepIn);
-  const int ns = __builtin_amdgcn_readfirstlane(a.ns), nd = __builtin_amdgcn_readfirstlane(a.nd);
+  const int ns = __builtin_amdgcn_readfirstlane(a.ns);
+  const int nd = NS > 0 ? ND : __builtin_amdgcn_readfirstlane(a.nd);
   const int preIdx = __builtin_amdgcn_readfirstlane(a.preIdx);
   const uint64_t opArg = uniform64(a.opArg);
   const bool post = __builtin_amdgcn_readfirstlane((int)a.post) != 0;
-  const uint32_t sysMask = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sysMask);
-  const char* s[NSA];
-#pragma unroll
-  for (int j = 0; j < NSA; j++) s[j] = uniformPtr(a.src[j]);
   const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
   const uint32_t lane16 = (uint32_t)tid * 16u;          // this thread's byte offset inside a row of nthr packs
   const uint32_t row = nthrU * 16u;                     // bytes between a thread's consecutive packs
   const size_t tile = (size_t)nthrU * U;
   size_t base = first;
-  for (; base + tile <= npacks; base += tileStep) {
-    const size_t b16 = base * 16;                       // uniform byte offset of this tile
-    u32x4 acc[U];
-    if (NS > 0) {
-      u32x4 v[NSA][U];
+
+  const int nLocal = NS > 0 ? LOC : __builtin_amdgcn_readfirstlane(a.nLocal);
+  auto storeTo = [&](uint64_t dk, bool wt, const u32x4 (&acc)[U], size_t b16) {
+    if (wt) {
+      const rsrc_t r = bufRsrc(dk);
+#pragma unroll
+      for (int u = 0; u < U; u++) stSysAt(r, (uint32_t)b16, lane16 + (uint32_t)u * row, acc[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; u++) stAt(dk + b16, lane16 + (uint32_t)u * row, acc[u]);
+    }
+  };
+
+  if (NS > 0) {
+    // every stream's base goes to scalar registers once: the argument block itself lives in scratch memory, and a
+    // scratch load inside the loop would be one more memory instruction to wait for
+    uint64_t s[NSA], d[NDA];
+#pragma unroll
+    for (int j = 0; j < NSA; j++) s[j] = (uint64_t)uniformPtr(a.src[j]);
+#pragma unroll
+    for (int k = 0; k < NDA; k++) d[k] = (uint64_t)uniformPtr(a.dst[k]);
+    u32x4 va[NSA][U], vb[NSA][U];
+    // the tile at `at`; !real: the same number of loads, all lanes from the first pack of the tile at `at` (a line this
+    // workgroup has just read: no branch, no traffic to speak of)
+    auto load = [&](u32x4 (&v)[NSA][U], size_t at, bool real) {
 #pragma unroll
       for (int j = 0; j < NSA; j++)
 #pragma unroll
-        for (int u = 0; u < U; u++) v[j][u] = ldAt((uint64_t)s[j] + b16, lane16 + (uint32_t)u * row);
+        for (int u = 0; u < U; u++) v[j][u] = ldAt(s[j] + at * 16, real ? lane16 + (uint32_t)u * row : 0u);
+    };
+    auto fold = [&](u32x4 (&cur)[NSA][U], size_t at) {
       if (OP == RA_OP_PREMULSUM) {
 #pragma unroll
         for (int j = 0; j < NSA; j++)
           if (j == preIdx) {
 #pragma unroll
-            for (int u = 0; u < U; u++) v[j][u] = packPre<T>(v[j][u], opArg);
+            for (int u = 0; u < U; u++) cur[j][u] = packPre<T>(cur[j][u], opArg);
           }
       }
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = v[0][u];
-#pragma unroll
       for (int j = 1; j < NSA; j++)
 #pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = packRed<T, OP>(acc[u], v[j][u]);
-    } else {
+        for (int u = 0; u < U; u++) cur[0][u] = packRed<T, OP>(cur[0][u], cur[j][u]);
+      if (OP == RA_OP_SUMPOSTDIV && post) {
+#pragma unroll
+        for (int u = 0; u < U; u++) cur[0][u] = packPost<T>(cur[0][u], opArg);
+      }
+#pragma unroll
+      for (int k = 0; k < NDA; k++) storeTo(d[k], k >= LOC, cur[0], at * 16);
+    };
+    if (!PIPE) {
+      for (; base + tile <= npacks; base += tileStep) { load(va, base, true); fold(va, base); }
+    } else if (base + tile <= npacks) {
+      load(va, base, true);
+      size_t nxt = base + tileStep;
+      bool more = nxt + tile <= npacks;
+      load(vb, more ? nxt : base, more);
+      fold(va, base);
+      base = nxt;
+      while (more) {                                   // the tile at `base` is in vb
+        nxt = base + tileStep;
+        more = nxt + tile <= npacks;
+        load(va, more ? nxt : base, more);
+        fold(vb, base);
+        base = nxt;
+        if (!more) break;
+        nxt = base + tileStep;
+        more = nxt + tile <= npacks;
+        load(vb, more ? nxt : base, more);
+        fold(va, base);
+        base = nxt;
+      }
+    }
+  } else {
+    for (; base + tile <= npacks; base += tileStep) {
+      const size_t b16 = base * 16;
+      u32x4 acc[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        acc[u] = ldAt((uint64_t)s[0] + b16, lane16 + (uint32_t)u * row);
+        acc[u] = ldAt((uint64_t)uniformPtr(a.src[0]) + b16, lane16 + (uint32_t)u * row);
         if (OP == RA_OP_PREMULSUM && preIdx == 0) acc[u] = packPre<T>(acc[u], opArg);
       }
       for (int j = 1; j < ns; j++) {
-        const char* sj = uniformPtr(a.src[j]) + b16;
+        const uint64_t sj = (uint64_t)uniformPtr(a.src[j]) + b16;
         u32x4 t[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) t[u] = ldAt((uint64_t)sj, lane16 + (uint32_t)u * row);
+        for (int u = 0; u < U; u++) t[u] = ldAt(sj, lane16 + (uint32_t)u * row);
 #pragma unroll
         for (int u = 0; u < U; u++) {
           if (OP == RA_OP_PREMULSUM && preIdx == j) t[u] = packPre<T>(t[u], opArg);
           acc[u] = packRed<T, OP>(acc[u], t[u]);
         }
       }
-    }
-    if (OP == RA_OP_SUMPOSTDIV && post) {
+      if (OP == RA_OP_SUMPOSTDIV && post) {
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], opArg);
-    }
-    for (int k = 0; k < nd; k++) {
-      char* d = uniformPtr(a.dst[k]) + b16;
-      if (sysMask >> k & 1) {
-#pragma unroll
-        for (int u = 0; u < U; u++) stSysAt((uint64_t)d, lane16 + (uint32_t)u * row, acc[u]);
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; u++) stAt((uint64_t)d, lane16 + (uint32_t)u * row, acc[u]);
+        for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], opArg);
       }
+      for (int k = 0; k < nd; k++) storeTo((uint64_t)uniformPtr(a.dst[k]), k >= nLocal, acc, b16);
     }
   }
   // Ragged end: the one tile that is not full, one pack per thread per pass.  Only the
@@ -351,7 +417,7 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
       }
       if (OP == RA_OP_SUMPOSTDIV && post) acc = packPost<T>(acc, opArg);
       for (int k = 0; k < nd; k++) {
-        if (sysMask >> k & 1) stSys((u32x4*)uniformPtr(a.dst[k]) + i, acc);
+        if (k >= nLocal) stSys((u32x4*)uniformPtr(a.dst[k]) + i, acc);
         else stPack((u32x4*)uniformPtr(a.dst[k]) + i, acc);
       }
     }
@@ -384,7 +450,7 @@ __device__ __forceinline__ void rcElems(const RcArgs& a, size_t nelem, size_t fi
     }
     if (OP == RA_OP_SUMPOSTDIV && a.post) acc = Scale<T>::post(acc, a.opArg);
     for (int k = 0; k < a.nd; k++) {
-      if (a.sysMask >> k & 1) stSysElem<T>((T*)a.dst[k] + i, acc);
+      if (k >= a.nLocal) stSysElem<T>((T*)a.dst[k] + i, acc);
       else ((T*)a.dst[k])[i] = acc;
     }
   }
@@ -397,31 +463,40 @@ __device__ __forceinline__ bool rcAligned(const RcArgs& a) {
   return (m & 15) == 0;
 }
 
-// One source-count case: full tiles of nthr*U packs are dealt round-robin to the `nparts`
+// One (source count, destination count) case: full tiles of nthr*U packs are dealt round-robin to the `nparts`
 // workgroups taking part; the ragged last tile goes to whoever owns that tile index.
-template <typename T, int OP, int NS, int U>
+template <typename T, int OP, int LOC, int NS, int U, int ND, bool PIPE = true>
 __device__ __forceinline__ void rcCase(const RcArgs& a, size_t npacks, int tid, int nthr, int part, int nparts) {
   const size_t tile = (size_t)nthr * U;
   const size_t nfull = npacks / tile;
   const bool ownsRagged = (nfull % nparts) == (size_t)part;
   const size_t lim = ownsRagged ? npacks : nfull * tile;
-  rcPacks<T, OP, NS, U>(a, lim, (size_t)part * tile, (size_t)nparts * tile, tid, nthr);
+  rcPacks<T, OP, LOC, NS, U, ND, PIPE>(a, lim, (size_t)part * tile, (size_t)nparts * tile, tid, nthr);
 }
 
 // Work-shared reduce-copy of `nelem` elements.  `part` of `nparts` workgroups take part
 // (the collectives use one workgroup: part 0 of 1; the local kernels use the whole grid).
-template <typename T, int OP>
+// The (sources, destinations, local destinations) shapes the schedules use at 2, 4 and 8 ranks get the pipelined loop
+// (sources x packs per thread = 8 loads, 128 B, per tile and thread in every case): one destination, local (local
+// kernels, reduce-scatter and reduce) or remote (ring and chain hops); as many destinations as sources with the first
+// one local (the all-pairs reducer; the ring's and chain's last reducing hop).  Every other shape takes the plain loop.
+template <typename T, int OP, bool PIPE>
 __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int tid, int nthr, int part, int nparts) {
   if (nelem == 0 || a.nd == 0) return;
   if (rcAligned(a)) {
     const size_t npacks = nelem * sizeof(T) / 16;
-    switch (a.ns) {
-      // sources x packs per thread = 8 loads (128 B) in flight per thread in every case
-      case 1: rcCase<T, OP, 1, 8>(a, npacks, tid, nthr, part, nparts); break;
-      case 2: rcCase<T, OP, 2, 4>(a, npacks, tid, nthr, part, nparts); break;
-      case 4: rcCase<T, OP, 4, 2>(a, npacks, tid, nthr, part, nparts); break;
-      case 8: rcCase<T, OP, 8, 1>(a, npacks, tid, nthr, part, nparts); break;
-      default: rcCase<T, OP, 0, 2>(a, npacks, tid, nthr, part, nparts); break;
+    const int shape = __builtin_amdgcn_readfirstlane(a.ns * 256 + a.nd * 16 + a.nLocal);
+    switch (shape) {
+      case 1 * 256 + 1 * 16 + 0: rcCase<T, OP, 0, 1, 8, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 1 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 1, 8, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 2 * 256 + 1 * 16 + 0: rcCase<T, OP, 0, 2, 4, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 2 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 2, 4, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 4 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 4, 2, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 8 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 8, 1, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 2 * 256 + 2 * 16 + 1: rcCase<T, OP, 1, 2, 4, 2, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 4 * 256 + 4 * 16 + 1: rcCase<T, OP, 1, 4, 2, 4, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      case 8 * 256 + 8 * 16 + 1: rcCase<T, OP, 1, 8, 1, 8, PIPE>(a, npacks, tid, nthr, part, nparts); break;
+      default: rcCase<T, OP, 0, 0, 2, 0, PIPE>(a, npacks, tid, nthr, part, nparts); break;
     }
     const size_t done = npacks * (16 / sizeof(T));
     if (done < nelem && part == 0) rcElems<T, OP>(a, nelem, done, nthr, tid);
@@ -434,13 +509,29 @@ __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int ti
 // (type, op) pair carries one copy of the loops however many schedule steps use them.
 template <typename T, int OP>
 __device__ __noinline__ void rcWG(const RcArgs& a, size_t nelem, int tid, int nthr) {
-  reduceCopy<T, OP>(a, nelem, tid, nthr, 0, 1);
+  reduceCopy<T, OP, true>(a, nelem, tid, nthr, 0, 1);
 }
-// One source to a.nd destinations, any element type.
+// One source to a.nd destinations, any element type (1, 2, 3, 4, 7 and 8 destinations are what the all-gather,
+// broadcast, ring and chain schedules ask for at 2, 4 and 8 ranks; the first one may be local).
+template <int LOC>
+static __device__ __forceinline__ void copyShapes(const RcArgs& a, size_t np, int tid, int nthr) {
+  switch (__builtin_amdgcn_readfirstlane(a.nd)) {
+    case 1: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 1>(a, np, tid, nthr, 0, 1); break;
+    case 2: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 2>(a, np, tid, nthr, 0, 1); break;
+    case 3: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 3>(a, np, tid, nthr, 0, 1); break;
+    case 4: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 4>(a, np, tid, nthr, 0, 1); break;
+    case 7: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 7>(a, np, tid, nthr, 0, 1); break;
+    case 8: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 8>(a, np, tid, nthr, 0, 1); break;
+    default: rcCase<int8_t, RA_OP_SUM, 0, 0, 2, 0>(a, np, tid, nthr, 0, 1); break;
+  }
+}
 static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int tid, int nthr) {
   if (nbytes == 0 || a.nd == 0) return;
   if (rcAligned(a)) {
-    rcCase<int8_t, RA_OP_SUM, 1, 8>(a, nbytes / 16, tid, nthr, 0, 1);
+    const int nLocal = __builtin_amdgcn_readfirstlane(a.nLocal);
+    if (nLocal == 0) copyShapes<0>(a, nbytes / 16, tid, nthr);
+    else if (nLocal == 1) copyShapes<1>(a, nbytes / 16, tid, nthr);
+    else rcCase<int8_t, RA_OP_SUM, 0, 0, 2, 0>(a, nbytes / 16, tid, nthr, 0, 1);
     const size_t done = nbytes & ~(size_t)15;
     if (done < nbytes) rcElems<int8_t, RA_OP_SUM>(a, nbytes, done, nthr, tid);
   } else {
@@ -449,39 +540,64 @@ static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int t
 }
 
 // Up to RA_MAX_SRCS independent copies src[j] -> dst[j] of `nbytes` each in ONE pass: every thread keeps
-// pairs x rows = up to 8 16-byte loads in flight (ROWS consecutive 16 KiB rows of every pair per iteration), so
-// the n-1 pieces a scatter or gather role moves per round share a single load-latency ramp instead of paying
-// it once per piece, and a single pair (2 ranks) still has eight loads in flight per thread.
-template <int ROWS>
-__device__ __forceinline__ size_t pairRows(const uint64_t* s, const uint64_t* d, int np, uint32_t sysMask, size_t nbytes,
-                                           uint32_t lane16, size_t row) {
-  constexpr int NP = RA_MAX_SRCS / ROWS;            // pairs this instantiation can hold
+// pairs x rows = up to 8 16-byte loads of a span in flight (ROWS consecutive 16 KiB rows of every pair), so the n-1
+// pieces a scatter or gather role moves per round share a single load-latency ramp instead of paying it once per
+// piece, and a single pair (2 ranks) still has eight loads in flight per thread.  Pipelined like rcPacks: the next
+// span's loads are issued before this span's stores, two register sets, first span peeled, NP exact.
+template <bool WT, int NP, int ROWS>
+__device__ __forceinline__ size_t pairRows(const uint64_t* sIn, const uint64_t* dIn, size_t nbytes, uint32_t lane16, size_t row) {
   const size_t span = row * ROWS;
   const size_t full = nbytes / span * span;
-  for (size_t b = 0; b < full; b += span) {
-    u32x4 v[NP][ROWS];
+  if (full == 0) return 0;
+  uint64_t s[NP], d[NP];
+#pragma unroll
+  for (int j = 0; j < NP; j++) { s[j] = sIn[j]; d[j] = dIn[j]; }
+  u32x4 va[NP][ROWS], vb[NP][ROWS];
+  auto load = [&](u32x4 (&v)[NP][ROWS], size_t b, bool real) {
 #pragma unroll
     for (int j = 0; j < NP; j++)
 #pragma unroll
-      for (int r = 0; r < ROWS; r++)
-        if (j < np) v[j][r] = ldAt(s[j] + b + (size_t)r * row, lane16);
+      for (int r = 0; r < ROWS; r++) v[j][r] = ldAt(s[j] + b + (real ? (size_t)r * row : 0), real ? lane16 : 0u);
+  };
+  auto store = [&](u32x4 (&v)[NP][ROWS], size_t b) {
 #pragma unroll
-    for (int j = 0; j < NP; j++)
+    for (int j = 0; j < NP; j++) {
+      if (WT) {
+        const rsrc_t rd = bufRsrc(d[j]);
 #pragma unroll
-      for (int r = 0; r < ROWS; r++)
-        if (j < np) {
-          if (sysMask >> j & 1) stSysAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
-          else stAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
-        }
+        for (int r = 0; r < ROWS; r++) stSysAt(rd, (uint32_t)(b + (size_t)r * row), lane16, v[j][r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) stAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
+      }
+    }
+  };
+  size_t b = 0;
+  load(va, 0, true);
+  bool more = span < full;
+  load(vb, more ? span : 0, more);
+  store(va, 0);
+  b = span;
+  while (more) {                                       // the span at b is in vb
+    more = b + span < full;
+    load(va, more ? b + span : b, more);
+    store(vb, b);
+    b += span;
+    if (!more) break;
+    more = b + span < full;
+    load(vb, more ? b + span : b, more);
+    store(va, b);
+    b += span;
   }
   return full;
 }
 
+// WT: the destinations are windows (write-through stores: the scatter role); otherwise local memory (the gather role).
+template <bool WT>
 static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn, int tid, int nthr) {
   const int np = __builtin_amdgcn_readfirstlane(a.ns);
   const size_t nbytes = uniform64(nbytesIn);
   if (nbytes == 0 || np == 0) return;
-  const uint32_t sysMask = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sysMask);
   uintptr_t m = 0;
   for (int j = 0; j < np; j++) m |= (uintptr_t)a.src[j] | (uintptr_t)a.dst[j];
   const bool aligned = (uniform64(m) & 15) == 0;
@@ -496,12 +612,25 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
       s[j] = uniform64((uint64_t)a.src[j < np ? j : 0]);
       d[j] = uniform64((uint64_t)a.dst[j < np ? j : 0]);
     }
-    if (np == 1) done = pairRows<8>(s, d, np, sysMask, nbytes, lane16, row);
-    else if (np == 2) done = pairRows<4>(s, d, np, sysMask, nbytes, lane16, row);
-    else if (np <= 4) done = pairRows<2>(s, d, np, sysMask, nbytes, lane16, row);
-    // the rest (and everything for 5 to 8 pairs) one row of every pair at a time
+    // spans of rows x pairs = up to 8 loads per thread, then what is left one row of every pair at a time
+    switch (np) {
+      case 1: done = pairRows<WT, 1, 8>(s, d, nbytes, lane16, row); break;
+      case 2: done = pairRows<WT, 2, 4>(s, d, nbytes, lane16, row); break;
+      case 3: done = pairRows<WT, 3, 2>(s, d, nbytes, lane16, row); break;
+      case 4: done = pairRows<WT, 4, 2>(s, d, nbytes, lane16, row); break;
+      default: break;
+    }
     for (int j = 0; j < RA_MAX_SRCS; j++) { s[j] += done; d[j] += done; }
-    done += pairRows<1>(s, d, np, sysMask, nbytes - done, lane16, row);
+    switch (np) {
+      case 1: done += pairRows<WT, 1, 1>(s, d, nbytes - done, lane16, row); break;
+      case 2: done += pairRows<WT, 2, 1>(s, d, nbytes - done, lane16, row); break;
+      case 3: done += pairRows<WT, 3, 1>(s, d, nbytes - done, lane16, row); break;
+      case 4: done += pairRows<WT, 4, 1>(s, d, nbytes - done, lane16, row); break;
+      case 5: done += pairRows<WT, 5, 1>(s, d, nbytes - done, lane16, row); break;
+      case 6: done += pairRows<WT, 6, 1>(s, d, nbytes - done, lane16, row); break;
+      case 7: done += pairRows<WT, 7, 1>(s, d, nbytes - done, lane16, row); break;
+      default: done += pairRows<WT, 8, 1>(s, d, nbytes - done, lane16, row); break;
+    }
   }
   // what is left (ragged end, or everything when a pointer is unaligned): pair by pair, bytes
   if (done < nbytes) {
@@ -509,7 +638,7 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
       const int8_t* sj = (const int8_t*)uniformPtr(a.src[j]);
       int8_t* dj = (int8_t*)uniformPtr(a.dst[j]);
       for (size_t i = done + tid; i < nbytes; i += nthr) {
-        if (sysMask >> j & 1) stSysElem<int8_t>(dj + i, sj[i]);
+        if (WT) stSysElem<int8_t>(dj + i, sj[i]);
         else dj[i] = sj[i];
       }
     }
@@ -519,10 +648,15 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
 // A pre-multiply scalar that lives in device memory (ncclScalarDevice) is read when the kernel runs, never on the
 // host at enqueue time: a captured launch replays with whatever the scalar holds then (the reference dereferences
 // it on the device as well, src/device/reduce_kernel.h:364-457 with scalarArgIsPtr).
+// System-scope loads: the scalar may have been rewritten by a copy engine since an earlier launch read it, and a launch
+// replayed from a graph does not necessarily start by dropping cached lines.
 template <typename T> __device__ __forceinline__ uint64_t loadScalarArg(const void* p) {
-  union { uint64_t u; T t; } x; x.u = 0;
-  x.t = *(const T*)p;
-  return uniform64(x.u);
+  uint64_t u;
+  if constexpr (sizeof(T) == 1) u = __hip_atomic_load((const uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else if constexpr (sizeof(T) == 2) u = __hip_atomic_load((const uint16_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else if constexpr (sizeof(T) == 4) u = __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else u = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return uniform64(u);
 }
 
 // ------------------------------------------------------------------ local kernels
@@ -530,7 +664,7 @@ template <typename T> __device__ __forceinline__ uint64_t loadScalarArg(const vo
 template <typename T, int OP>
 __global__ __launch_bounds__(1024) void raLocalKernel(RcArgs a, size_t nelem, const void* opArgPtr) {
   if (OP == RA_OP_PREMULSUM && opArgPtr) a.opArg = loadScalarArg<T>(opArgPtr);
-  reduceCopy<T, OP>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
+  reduceCopy<T, OP, false>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ inter-GPU protocol
@@ -661,11 +795,11 @@ struct Ctx {
     __syncthreads();
     if (timed) sh->ts[3] = wall_clock64();
     if (tid < 64) {
-      // Release before the flag.  Window data is written with system-scope write-through stores and every
-      // wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of the flag
-      // store; the fence adds the L2 write-back the reference also performs before posting a step on GFX9
-      // (prims_simple.h:168-171).  It costs about 0.5 ms of a 2.3 ms two-rank 1 GiB loop-back all-reduce and
-      // nothing measurable once a link is the bound.  tuneFlags 1 = no fence, 4 = system scope.
+      // Release before the flag.  Everything this workgroup stored in the body went out as system-scope write-through
+      // stores and every wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of
+      // the flag store; the fence adds the L2 write-back the reference also performs before posting a step on GFX9
+      // (prims_simple.h:168-171).  With no dirty lines of this kernel in L2 it is cheap.  tuneFlags 1 = no fence,
+      // 4 = system scope.
       if (sendMask && !(comm->tuneFlags & 1)) {
         if (comm->tuneFlags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -701,7 +835,8 @@ struct Ctx {
       sh->tk[0] += sh->ts[1] - sh->ts[0]; sh->tk[1] += sh->ts[2] - sh->ts[1]; sh->tk[2] += sh->ts[3] - sh->ts[2];
       sh->tk[3] += t4 - sh->ts[3]; sh->tk[4] += 1;
     }
-    __syncthreads();
+    // No barrier here: the counters wave 0 has just advanced are next read by wave 0 itself (the waits of the following
+    // step) and by everybody only behind that step's first barrier, which wave 0 reaches after these writes.
     return ok;
   }
 };
@@ -761,14 +896,14 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
           size_t off, ne; R.piece(g, p, off, ne);
           if (i == 0) ne0 = ne; else same = same && ne == ne0;
-          pa.src[i] = (const char*)(in + off); pa.dst[i] = cx.sendSlot(p, 0); pa.sysMask |= 1u << i;
+          pa.src[i] = (const char*)(in + off); pa.dst[i] = cx.sendSlot(p, 0);
         }
-        if (same) { pairCopyWG(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
+        if (same) { pairCopyWG<true>(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 0; i < n - 1; i++) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0);
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         }
       });
@@ -793,12 +928,12 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
         size_t off, ne; R.piece(g, r, off, ne);
         RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
         for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off);
+        a.dst[0] = (char*)(out + off); a.nLocal = 1;
         int k = 1, nDirect = 0;
         for (int i = 1; i < n; i++) {
           const int p = (r + i) % n;
           const uint64_t base = cx.sh->directBase[p];
-          a.sysMask |= 1u << k;
+         
           a.dst[k++] = base ? (char*)base + off * sizeof(T) : cx.sendSlot(p, 1);
           nDirect += base != 0;
         }
@@ -823,13 +958,13 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
         }
         pa.ns = np; pa.nd = np;
         if (np == 0) return;
-        if (same) { pairCopyWG(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
+        if (same) { pairCopyWG<false>(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
           if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = (char*)(out + off);
+          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = (char*)(out + off); a.nLocal = 1;
           copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
         }
       });
@@ -856,15 +991,15 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
           RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
           for (int i = 0; i < n - 1; i++) {
             const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
-            pa.src[i] = (const char*)(in + (size_t)p * w.count + off); pa.dst[i] = cx.sendSlot(p, 0); pa.sysMask |= 1u << i;
+            pa.src[i] = (const char*)(in + (size_t)p * w.count + off); pa.dst[i] = cx.sendSlot(p, 0);
           }
-          pairCopyWG(pa, ne * sizeof(T), cx.tid, cx.nthr);
+          pairCopyWG<true>(pa, ne * sizeof(T), cx.tid, cx.nthr);
           return;
         }
         for (int i = 0; i < n - 1; i++) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0); a.sysMask |= 1u << 0;
+          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0);
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         }
       });
@@ -873,7 +1008,7 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
         RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
         for (int j = 0; j < n; j++)
           a.src[j] = (j == r) ? (const char*)(in + (size_t)r * w.count + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off);
+        a.dst[0] = (char*)(out + off); a.nLocal = 1;
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
@@ -928,11 +1063,11 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
         a.src[0] = w.send + off;
         int k = 0, nDirect = 0;
         char* mine = w.recv + (size_t)r * nbytes + off;
-        if (mine != w.send + off) a.dst[k++] = mine;
+        if (mine != w.send + off) { a.dst[k++] = mine; a.nLocal = 1; }
         for (int i = 1; i < n; i++) {
           const int p = (r + i) % n;
           const uint64_t base = cx.sh->directBase[p];
-          a.sysMask |= 1u << k;
+         
           a.dst[k++] = base ? (char*)base + (size_t)r * nbytes + off : cx.sendSlot(p, 1);
           nDirect += base != 0;
         }
@@ -955,7 +1090,7 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
           pa.src[np] = cx.recvSlot(p, 1); pa.dst[np] = w.recv + (size_t)p * nbytes + off; np++;
         }
         pa.ns = np; pa.nd = np;
-        if (np) pairCopyWG(pa, nb, cx.tid, cx.nthr);
+        if (np) pairCopyWG<false>(pa, nb, cx.tid, cx.nthr);
       });
     }
   }
@@ -980,15 +1115,15 @@ __device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
         RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = w.send + off;
         int k = 0;
-        if (w.recv != w.send) a.dst[k++] = w.recv + off;
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(p, 1); }
+        if (w.recv != w.send) { a.dst[k++] = w.recv + off; a.nLocal = 1; }
+        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
         a.nd = k;
         copyWG(a, nb, cx.tid, cx.nthr);
       });
     } else {
       cx.step(1u << root, 1, 0, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = cx.recvSlot(root, 1); a.dst[0] = w.recv + off;
+        a.src[0] = cx.recvSlot(root, 1); a.dst[0] = w.recv + off; a.nLocal = 1;
         copyWG(a, nb, cx.tid, cx.nthr);
       });
     }
@@ -1011,14 +1146,14 @@ __device__ void directReduce(Ctx& cx, const RaWork& w, int role) {
     if (role == 0) {
       cx.step(0, 0, 1u << root, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-        a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(root, 0); a.sysMask |= 1u << 0;
+        a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(root, 0);
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     } else {
       cx.step(peers, 0, 0, 0, [&]() {
         RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
         for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off);
+        a.dst[0] = (char*)(out + off); a.nLocal = 1;
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
@@ -1055,7 +1190,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
     R.piece(g, (rp.ix + n - 1) % n, off, ne);
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
+      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0);
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: local + received -> next
@@ -1064,7 +1199,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
         a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
+        a.dst[0] = cx.sendSlot(rp.next, 0);
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
@@ -1073,7 +1208,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
     cx.step(pm, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
       a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
+      a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: keep and forward finished pieces
@@ -1082,7 +1217,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
+        a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
         copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
       });
     }
@@ -1090,7 +1225,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
     R.piece(g, (rp.ix + 1) % n, off, ne);
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = (char*)(out + off);
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = (char*)(out + off); a.nLocal = 1;
       copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
     });
   }
@@ -1112,7 +1247,7 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
     int blk = rp.order[(rp.ix + n - 1) % n];
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
+      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0);
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
     for (int j = 2; j < n; j++) {
@@ -1120,14 +1255,14 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
         a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 0;
+        a.dst[0] = cx.sendSlot(rp.next, 0);
         rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
       });
     }
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
       a.src[0] = (const char*)(in + (size_t)cx.rank * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = (char*)(out + off);
+      a.dst[0] = (char*)(out + off); a.nLocal = 1;
       rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
     });
   }
@@ -1149,8 +1284,8 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
       a.src[0] = w.send + off;
       int k = 0;
       char* mine = w.recv + (size_t)cx.rank * nbytes + off;
-      if (mine != w.send + off) a.dst[k++] = mine;
-      a.sysMask |= 1u << k; a.dst[k++] = cx.sendSlot(rp.next, 0);
+      if (mine != w.send + off) { a.dst[k++] = mine; a.nLocal = 1; }
+      a.dst[k++] = cx.sendSlot(rp.next, 0);
       a.nd = k;
       copyWG(a, nb, cx.tid, cx.nthr);
     });
@@ -1159,14 +1294,14 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.dst[1] = cx.sendSlot(rp.next, 0); a.sysMask |= 1u << 1;
+        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
         copyWG(a, nb, cx.tid, cx.nthr);
       });
     }
     const int blk = rp.order[(rp.ix + 1) % n];
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = w.recv + (size_t)blk * nbytes + off;
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.nLocal = 1;
       copyWG(a, nb, cx.tid, cx.nthr);
     });
   }
@@ -1195,21 +1330,21 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
       if (leaf) {
         cx.step(0, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0); a.sysMask |= 1u << 0;
+          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0);
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       } else if (!root) {
         cx.step(1u << child, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = cx.sendSlot(parent, 0); a.sysMask |= 1u << 0;
+          a.dst[0] = cx.sendSlot(parent, 0);
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       } else {
         cx.step(1u << child, 0, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
           a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1); a.sysMask |= 1u << 1;
+          a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
           rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
         });
       }
@@ -1218,14 +1353,14 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
       if (leaf) {
         cx.step(1u << parent, 1, 0, 0, [&]() {
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = (char*)(out + off);
+          a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = (char*)(out + off); a.nLocal = 1;
           copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       } else {
         cx.step(1u << parent, 1, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
           a.src[0] = cx.recvSlot(parent, 1);
-          a.dst[0] = (char*)(out + off); a.dst[1] = cx.sendSlot(child, 1); a.sysMask |= 1u << 1;
+          a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
           copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       }

@@ -197,7 +197,7 @@ ncclResult_t raNetSetup(ncclComm* c) {
   // pinned, GPU-mapped host memory (the reference: ncclCudaHostCalloc, src/transport/net.cc:798-800)
   for (int p = 0; p < N->n; p++) {
     void* h = nullptr;
-    RA_HIP(hipHostMalloc(&h, bytes, hipHostMallocMapped));
+    RA_HIP(hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocCoherent));   // CPU threads and kernels exchange data through it
     memset(h, 0, c->lay.dataOffset);
     void* d = nullptr;
     RA_HIP(hipHostGetDevicePointer(&d, h, 0));

@@ -9,6 +9,7 @@ exercised on a one-GPU box.
 
 Children import torch and the HIP library; the parent only needs numpy.
 """
+import ctypes
 import multiprocessing as mp
 import os
 import traceback
@@ -18,28 +19,40 @@ import numpy as np
 COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_ALLGATHER, COLL_BROADCAST, COLL_REDUCE = 0, 1, 2, 3, 4
 
 
+def ctypes_hip():
+    if _DevBuf._hip is None:
+        _DevBuf._hip = ctypes.CDLL("libamdhip64.so")
+    return _DevBuf._hip
+
+
 class _DevBuf:
-    """A raw device allocation filled and read with hipMemcpy (no torch tensor): `fine` = ncclMemAlloc (fine-grained,
-    what a peer may write into), else plain hipMalloc (coarse-grained)."""
+    """A device buffer that stays at one address across commands.  `fine` = ncclMemAlloc (fine-grained memory, what a
+    peer may write into), moved with hipMemcpy / hipMemset; otherwise an ordinary torch tensor (coarse-grained memory
+    from torch's caching allocator), moved by torch."""
 
     _hip = None
 
-    def __init__(self, ra, nbytes, fine, fill=None, image=None):
-        import ctypes
-        if _DevBuf._hip is None:
-            _DevBuf._hip = ctypes.CDLL("libamdhip64.so")
-        self.ct, self.ra, self.n, self.fine = ctypes, ra, int(nbytes), fine
+    def __init__(self, ra, nbytes, fine=False, fill=None, image=None):
+        import torch
+        ctypes_hip()
+        if image is not None:
+            image = np.ascontiguousarray(image).view(np.uint8).ravel()
+            nbytes = image.size
+        self.ra, self.n, self.fine, self.torch = ra, int(nbytes), fine, torch
         if fine:
             self.p = ra.mem_alloc(max(self.n, 16))
+            self.t = None
+        elif image is not None and self.n:
+            self.t = torch.from_numpy(image).cuda()       # one host-to-device copy
+            torch.cuda.synchronize()
+            self.p = self.t.data_ptr()
+            return
         else:
-            q = ctypes.c_void_p()
-            rc = self._hip.hipMalloc(ctypes.byref(q), ctypes.c_size_t(max(self.n, 16)))
-            if rc != 0:
-                raise RuntimeError(f"hipMalloc failed with {rc}")
-            self.p = q.value
+            self.t = torch.empty(max(self.n, 16), dtype=torch.uint8, device="cuda")
+            self.p = self.t.data_ptr()
         if fill is not None:
             self.fill(fill)
-        if image is not None:
+        if image is not None and self.n:
             self.write(0, image)
 
     def data_ptr(self):
@@ -48,34 +61,45 @@ class _DevBuf:
     def numel(self):
         return self.n
 
-    def fill(self, value):
-        rc = self._hip.hipMemset(self.ct.c_void_p(self.p), self.ct.c_int(value), self.ct.c_size_t(self.n))
+    def fill(self, value, off=0, n=None):
+        n = self.n - off if n is None else n
+        if self.t is not None:
+            self.t[off:off + n].fill_(value)
+            self.torch.cuda.synchronize()
+            return
+        rc = self._hip.hipMemset(ctypes.c_void_p(self.p + off), ctypes.c_int(value), ctypes.c_size_t(n))
         rc = rc or self._hip.hipDeviceSynchronize()
         if rc != 0:
             raise RuntimeError(f"hipMemset failed with {rc}")
 
     def write(self, off, image):
         image = np.ascontiguousarray(image).view(np.uint8).ravel()
-        rc = self._hip.hipMemcpy(self.ct.c_void_p(self.p + off), self.ct.c_void_p(image.ctypes.data),
-                                 self.ct.c_size_t(image.size), self.ct.c_int(1))
+        if self.t is not None:
+            self.t[off:off + image.size].copy_(self.torch.from_numpy(image))
+            self.torch.cuda.synchronize()
+            return
+        rc = self._hip.hipMemcpy(ctypes.c_void_p(self.p + off), ctypes.c_void_p(image.ctypes.data),
+                                 ctypes.c_size_t(image.size), ctypes.c_int(1))
         if rc != 0:
             raise RuntimeError(f"hipMemcpy to the device failed with {rc}")
 
     def read(self):
+        if self.t is not None:
+            self.torch.cuda.synchronize()
+            return self.t[:self.n].cpu().numpy()
         out = np.empty(self.n, dtype=np.uint8)
-        rc = self._hip.hipMemcpy(self.ct.c_void_p(out.ctypes.data), self.ct.c_void_p(self.p), self.ct.c_size_t(self.n),
-                                 self.ct.c_int(2))
+        rc = self._hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(self.p), ctypes.c_size_t(self.n),
+                                 ctypes.c_int(2))
         if rc != 0:
             raise RuntimeError(f"hipMemcpy from the device failed with {rc}")
         return out
 
     def free(self):
-        if self.p:
-            if self.fine:
-                self.ra.mem_free(self.p)
-            else:
-                self._hip.hipFree(self.ct.c_void_p(self.p))
-            self.p = 0
+        if self.t is not None:
+            self.t = None
+        elif self.p:
+            self.ra.mem_free(self.p)
+        self.p = 0
 
 
 def _child(rank, nranks, device, conn, env):
@@ -124,24 +148,24 @@ def _child(rank, nranks, device, conn, env):
                 es = ra.TYPE_SIZE[a["dtype"]]
                 host_in = np.frombuffer(a["input"], dtype=np.uint8)
 
+                bufs = []
+
                 def upload(image):
-                    """One host-to-device copy per buffer; it must read back as written."""
-                    t = torch.from_numpy(image).cuda()
-                    torch.cuda.synchronize()
-                    if not np.array_equal(t.cpu().numpy(), image):
+                    """One host-to-device copy per buffer (torch memory); it must read back as written."""
+                    b = _DevBuf(ra, 0, image=image)
+                    if not np.array_equal(b.read(), np.ascontiguousarray(image).view(np.uint8).ravel()):
                         raise RuntimeError("test bed: a host-to-device upload does not read back as written")
-                    return t
+                    bufs.append(b)
+                    return b
 
                 # pad = (bytes in front of sendbuff, bytes in front of recvbuff): unaligned user pointers.  Every
                 # buffer ends in a 64-byte guard that must come back untouched.
                 pad_s, pad_r = a.get("pad") or (0, 0)
                 GUARD = 64
-                managed = []
                 if a.get("managed"):
                     # hipMallocManaged buffers (the reference's managed-memory test mode, TestBedChild.cpp ALLOCATE_MEM):
-                    # filled and read back through the host mapping, no torch tensor involved.
-                    import ctypes
-                    hip = ctypes.CDLL("libamdhip64.so")
+                    # filled and read back through the host mapping.
+                    hip = ctypes_hip()
 
                     class Managed:
                         def __init__(self, image):
@@ -152,15 +176,22 @@ def _child(rank, nranks, device, conn, env):
                                 raise RuntimeError(f"hipMallocManaged failed with {rc}")
                             self.p = p.value
                             ctypes.memmove(self.p, image.ctypes.data, self.n)
-                            managed.append(self)
+                            bufs.append(self)
 
                         def data_ptr(self):
                             return self.p
 
-                        def cpu(self):
+                        def read(self):
                             out = np.empty(self.n, dtype=np.uint8)
                             ctypes.memmove(out.ctypes.data, self.p, self.n)
-                            return torch.from_numpy(out)
+                            return out
+
+                        def fill(self, value, off=0, n=None):
+                            ctypes.memset(self.p + off, value, self.n - off if n is None else n)
+
+                        def write(self, off, image):
+                            image = np.ascontiguousarray(image).view(np.uint8).ravel()
+                            ctypes.memmove(self.p + off, image.ctypes.data, image.size)
 
                         def free(self):
                             hip.hipFree(ctypes.c_void_p(self.p))
@@ -194,9 +225,9 @@ def _child(rank, nranks, device, conn, env):
                 scal_dev = scal_next = None
                 if a.get("premul") is not None and a.get("premul_device"):
                     # the scalar lives in device memory (ncclScalarDevice): the kernel reads it when it runs
-                    scal_dev = torch.from_numpy(np.frombuffer(a["premul"], dtype=np.uint8).copy()).cuda()
+                    scal_dev = upload(np.frombuffer(a["premul"], dtype=np.uint8).copy())
                     if a.get("premul2") is not None:
-                        scal_next = torch.from_numpy(np.frombuffer(a["premul2"], dtype=np.uint8).copy()).cuda()
+                        scal_next = np.frombuffer(a["premul2"], dtype=np.uint8).copy()
                     user_op = comm.create_premul_sum(None, a["dtype"], residence=ra.ncclScalarDevice, device_ptr=scal_dev.data_ptr())
                     op = user_op
                 elif a.get("premul") is not None:
@@ -226,9 +257,9 @@ def _child(rank, nranks, device, conn, env):
                     with torch.cuda.stream(stream):        # replays on the capture stream: no further hardware queue
                         g.replay()
                         stream.synchronize()
-                        out_view()[pad_r:pad_r + a["out_bytes"]].fill_(0x3C)
+                        out_view().fill(0x3C, pad_r, a["out_bytes"])
                         if scal_next is not None:
-                            scal_dev.copy_(scal_next)          # the second replay must pick the new scalar up
+                            scal_dev.write(0, scal_next)       # the second replay must pick the new scalar up
                         stream.synchronize()
                         g.replay()
                 with torch.cuda.stream(stream):
@@ -241,9 +272,9 @@ def _child(rank, nranks, device, conn, env):
                     comm.destroy_op(user_op)
                 err = comm.async_error()
                 torch.cuda.synchronize()
-                res = out_view().cpu().numpy()
-                for m in managed:
-                    m.free()
+                res = out_view().read()
+                for b in bufs:
+                    b.free()
                 for lo, hi in guards:
                     if not np.all(res[lo:hi] == 0xA5):
                         raise RuntimeError(f"rank {rank}: bytes outside the receive buffer were written (guard {lo}:{hi})")
@@ -323,6 +354,108 @@ def _child(rank, nranks, device, conn, env):
                     bf.free()
                 reg_state = None
                 conn.send(("ok", None))
+            elif cmd == "probe_poison":
+                # Diagnostic, no communicator involved: fill a buffer with poison, overwrite it with the library's local
+                # copy kernel on the side stream, read it back; variants of how the buffer is allocated and how it is
+                # read.  Returns {variant: (runs with wrong bytes, wrong bytes, of which poison)}.
+                import time
+                nbytes, reps = args["nbytes"], args.get("reps", 8)
+                rng = np.random.default_rng(1234 + rank)
+                image = rng.integers(0, 200, nbytes, dtype=np.uint8)
+                image[image == 0x5A] = 0x11
+                hip = ctypes_hip()
+                src_t = torch.from_numpy(image).cuda()
+                torch.cuda.synchronize()
+                found = {}
+
+                class _Raw:                       # hipMalloc / ncclMemAlloc with nothing else attached
+                    def __init__(self, fine):
+                        self.fine = fine
+                        if fine:
+                            self.p = ra.mem_alloc(nbytes)
+                        else:
+                            q = ctypes.c_void_p()
+                            if hip.hipMalloc(ctypes.byref(q), ctypes.c_size_t(nbytes)) != 0:
+                                raise RuntimeError("hipMalloc failed")
+                            self.p = q.value
+
+                    def data_ptr(self):
+                        return self.p
+
+                    def free(self):
+                        if self.fine:
+                            ra.mem_free(self.p)
+                        else:
+                            hip.hipFree(ctypes.c_void_p(self.p))
+
+                kept = _Raw(False)
+                for variant in args.get("variants", ("fresh/dma", "fresh/dma-late", "fresh/kernel", "fresh-nofree/dma", "reuse/dma", "torch/dma", "fine-fresh/dma",
+                                "fresh/dma/writer-null", "fresh/dma/plainstores")):
+                    parts = variant.split("/")
+                    alloc, read = parts[0], parts[1]
+                    extra = parts[2] if len(parts) > 2 else ""
+                    bad_runs = bad_bytes = poison_bytes = 0
+                    leak = []
+                    hist = []
+                    for _ in range(reps):
+                        t = None
+                        if alloc == "torch":
+                            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                            ptr, buf = t.data_ptr(), None
+                        elif alloc == "reuse":
+                            ptr, buf = kept.data_ptr(), None
+                        else:
+                            buf = _Raw(alloc.startswith("fine"))
+                            ptr = buf.data_ptr()
+                        if extra == "settle":
+                            time.sleep(0.1)
+                        hip.hipMemset(ctypes.c_void_p(ptr), ctypes.c_int(0x5A), ctypes.c_size_t(nbytes))
+                        hip.hipDeviceSynchronize()
+                        if extra == "plainstores":
+                            # a torch kernel as the writer (plain stores) through a tensor that aliases nothing: copy into a
+                            # torch tensor is not possible for raw memory, so use hipMemcpyAsync D2D on the side stream
+                            hip.hipMemcpyAsync(ctypes.c_void_p(ptr), ctypes.c_void_p(src_t.data_ptr()), ctypes.c_size_t(nbytes), ctypes.c_int(3),
+                                               ctypes.c_void_p(stream.cuda_stream))
+                        else:
+                            ra.reduce_copy(ptr, [src_t], nbytes, ra.ncclInt8, ra.ncclSum, 0 if extra == "writer-null" else stream)
+                        stream.synchronize()
+                        torch.cuda.synchronize()
+                        if read == "dma-late":
+                            time.sleep(0.05)
+                        if read == "dma-after-sweep":
+                            sw = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+                            sw.fill_(1)
+                            int(sw.sum().item())
+                            del sw
+                            torch.cuda.synchronize()
+                        if read == "kernel":
+                            out_t = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+                            ra.reduce_copy(out_t, [ptr], nbytes, ra.ncclInt8, ra.ncclSum, stream)
+                            stream.synchronize()
+                            back = out_t.cpu().numpy()
+                        else:
+                            back = np.empty(nbytes, dtype=np.uint8)
+                            hip.hipMemcpy(ctypes.c_void_p(back.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), ctypes.c_int(2))
+                        wrong = back != image
+                        nb = int(wrong.sum())
+                        bad_runs += nb > 0
+                        bad_bytes += nb
+                        poison_bytes += int((back[wrong] == 0x5A).sum())
+                        if nb:
+                            vals, cnts = np.unique(back[wrong], return_counts=True)
+                            top = sorted(zip(cnts.tolist(), vals.tolist()), reverse=True)[:3]
+                            idx = np.nonzero(wrong)[0]
+                            hist.append((top, int(idx[0]), int(idx[-1])))
+                        if buf is not None:
+                            if alloc.endswith("nofree"):
+                                leak.append(buf)
+                            else:
+                                buf.free()
+                    for bf in leak:
+                        bf.free()
+                    found[variant] = (bad_runs, bad_bytes, poison_bytes, hist[:3])
+                kept.free()
+                conn.send(("ok", found))
             elif cmd == "second_comm":
                 # a second communicator over the same ranks, alive next to the first (a framework's DP + TP groups)
                 comm2 = ra.Communicator.init_rank(nranks, args, rank)
@@ -330,15 +463,18 @@ def _child(rank, nranks, device, conn, env):
             elif cmd == "interleave":
                 # args: dict(dtype, op, count, a(bytes), b(bytes)): first(a) second(b) first(b) second(a) on one stream
                 a = args
-                ta = torch.from_numpy(np.frombuffer(a["a"], dtype=np.uint8).copy()).cuda()
-                tb = torch.from_numpy(np.frombuffer(a["b"], dtype=np.uint8).copy()).cuda()
-                outs = [torch.from_numpy(np.full(ta.numel(), 0xA5, dtype=np.uint8)).cuda() for _ in range(4)]
+                ta = _DevBuf(ra, 0, image=np.frombuffer(a["a"], dtype=np.uint8))
+                tb = _DevBuf(ra, 0, image=np.frombuffer(a["b"], dtype=np.uint8))
+                outs = [_DevBuf(ra, ta.numel(), fill=0xA5) for _ in range(4)]
                 torch.cuda.synchronize()
                 for k, (c, src) in enumerate([(comm, ta), (comm2, tb), (comm, tb), (comm2, ta)]):
                     c.all_reduce(src.data_ptr(), outs[k].data_ptr(), a["count"], a["dtype"], a["op"], stream)
                 stream.synchronize()
                 errs = (comm.async_error(), comm2.async_error())
-                conn.send(("ok", (errs, [o.cpu().numpy().tobytes() for o in outs])))
+                got = [o.read().tobytes() for o in outs]
+                for b in [ta, tb] + outs:
+                    b.free()
+                conn.send(("ok", (errs, got)))
             elif cmd == "second_destroy":
                 comm2.destroy()
                 comm2 = None
