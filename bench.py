@@ -75,7 +75,8 @@ def main():
     if per_gpu > 1:
         # Loop-back mode (several ranks on one GPU, for kernel work on a one-GPU box): the ranks share
         # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
-        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // per_gpu)))
+        # (two ranks: two workgroups per channel, otherwise three)
+        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if n == 2 else 64) // per_gpu)))
 
     out = sys.stdout
     if n > 1:

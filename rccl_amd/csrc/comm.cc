@@ -59,11 +59,14 @@ void readTunables(ncclComm* c) {
   if (ch < 1) ch = 1;
   if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
   // Every workgroup of a launch waits for workgroups on other GPUs, so all of them must be resident at once:
-  // one 1024-thread workgroup per compute unit, three roles per channel in the all-reduce.
+  // one 1024-thread workgroup per compute unit, three roles per channel in the all-reduce (with two ranks the
+  // scatter and gather workgroups serve two channels each: two workgroups per channel).
   int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= 3 && ch > cus / 3) {
-    RA_INFO("device %d has %d compute units: %ld channels reduced to %d", c->device, cus, ch, cus / 3);
-    ch = cus / 3;
+  const int perChannel = c->nRanks == 2 ? 2 : 3;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= perChannel &&
+      ch > cus / perChannel) {
+    RA_INFO("device %d has %d compute units: %ld channels reduced to %d", c->device, cus, ch, cus / perChannel);
+    ch = cus / perChannel;
   }
   (void)hipGetLastError();
   c->maxChannels = (int)ch;

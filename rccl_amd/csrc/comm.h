@@ -91,6 +91,7 @@ ncclResult_t raCommPollError(ncclComm* comm);
 // enqueue.cc
 struct RaPlan {
   int algo, proto, nChannels, grid, block;
+  int pairRoles;             // RaWork::pairRoles
   size_t chunkElems, lastChunkElems;
 };
 struct RaCollArgs {

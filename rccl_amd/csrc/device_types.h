@@ -20,7 +20,7 @@
 #include <stdint.h>
 
 #define RA_MAX_RANKS 16
-#define RA_MAX_CHANNELS 64
+#define RA_MAX_CHANNELS 128
 #define RA_NKINDS 2
 #define RA_FLAG_STRIDE 128  // bytes between two flag words: one writer per line
 #define RA_MAX_SRCS 8   // sources / destinations of one reduce-copy
@@ -107,7 +107,7 @@ struct RaDevComm {
   uint32_t netMode;           // 1: windows are host-pinned staging areas pumped over TCP by a proxy thread
   const RaRegSlot* regTable;  // [RA_MAX_RANKS][RA_MAX_REGS]
   uint64_t* stats;            // [0] pieces written straight into a peer's receive buffer, [1] pieces sent through the FIFO (all-reduce gather phase)
-  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 1 = no release fence, 2 = no acquire fence (breaks results), 4 = system-scope release
+  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 2 = no acquire fence (breaks results), 8 = agent-scope release fence before flag posts, 8 + 4 = system-scope release, 32 = step timers
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
@@ -128,6 +128,7 @@ struct RaWork {
                          // (ncclScalarDevice; the reference's scalarArgIsPtr, src/enqueue.cc:1962-2057)
   uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
   int root;            // broadcast / reduce
+  int pairRoles;       // all-pairs all-reduce: scatter and gather workgroups serve two channels each (see raCollKernel)
   uint64_t regWord;    // announce word for recv (0: not registered)
   int peerRegs;        // some peer registration is mapped on this rank: read the peers' announce words
 };

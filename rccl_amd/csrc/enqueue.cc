@@ -136,9 +136,15 @@ thread_local std::vector<RaCollArgs> tPending;
 thread_local std::vector<InitJob> tInits;
 thread_local ncclResult_t tGroupError = ncclSuccess;
 
-int gridFor(int coll, int algo, int nCh) {
+// Two ranks, all-pairs all-reduce, an even number of channels: the scatter and gather workgroups serve two channels
+// each (a reducer step moves twice their bytes), so the launch has 2 x channels workgroups instead of 3 x.
+bool pairsRoles(int n, int coll, int algo, int nCh) {
+  return n == 2 && coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && nCh >= 2 && nCh % 2 == 0;
+}
+int gridFor(int n, int coll, int algo, int nCh) {
   if (algo == RA_ALGO_RING) return nCh;
   if (algo == RA_ALGO_TREE) return 2 * nCh;
+  if (pairsRoles(n, coll, algo, nCh)) return 2 * nCh;
   return (coll == RA_COLL_ALLREDUCE ? 3 : 2) * nCh;
 }
 
@@ -182,6 +188,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.chunkElems = p.chunkElems; w.lastChunkElems = p.lastChunkElems; w.opArg = arg; w.opArgPtr = argPtr;
   w.stepBytes = (uint32_t)(p.chunkElems * es);
   w.root = a.root;
+  w.pairRoles = p.pairRoles;
   if (a.coll == RA_COLL_ALLREDUCE && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net)
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
   if (a.coll == RA_COLL_ALLGATHER && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net && a.count * es >= RA_AG_ANNOUNCE_BYTES)
@@ -291,7 +298,8 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
     if (last > chunk) last = chunk;
     p->lastChunkElems = last;
   }
-  p->grid = gridFor(coll, algo, p->nChannels);
+  p->grid = gridFor(n, coll, algo, p->nChannels);
+  p->pairRoles = pairsRoles(n, coll, algo, p->nChannels) ? 1 : 0;
   // Small all-reduces on the all-pairs schedule take the one-shot low-latency protocol
   // (the reference switches to LL below 256-512 KiB, src/graph/tuning.cc:632-671).
   // Reduce-scatter and all-gather take it up to the same payload per rank: like the all-reduce they need every
@@ -306,6 +314,7 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   if (rooted && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
   if (allowLL && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
     p->proto = 1;
+    p->pairRoles = 0;
     p->nChannels = RA_LL_GRID;
     p->grid = RA_LL_GRID;
     p->block = RA_LL_THREADS;

@@ -795,12 +795,15 @@ struct Ctx {
     __syncthreads();
     if (timed) sh->ts[3] = wall_clock64();
     if (tid < 64) {
-      // Release before the flag.  Everything this workgroup stored in the body went out as system-scope write-through
-      // stores and every wave drained them (vmcnt(0)) before the barrier above, which by itself orders them ahead of
-      // the flag store; the fence adds the L2 write-back the reference also performs before posting a step on GFX9
-      // (prims_simple.h:168-171).  With no dirty lines of this kernel in L2 it is cheap.  tuneFlags 1 = no fence,
-      // 4 = system scope.
-      if (sendMask && !(comm->tuneFlags & 1)) {
+      // Nothing but the drain is needed before the flag.  Every byte this step handed to a peer went out as a
+      // system-scope write-through store (sc0 sc1), each wave waited for its own stores to be acknowledged (vmcnt(0))
+      // and all waves met at the barrier above, so those bytes are at their destination before the flag store is
+      // issued; the flag takes the same path behind them.  The reference posts plain stores and therefore needs the
+      // L2 write-back of __threadfence() first (prims_simple.h:168-171); here that write-back would only flush the
+      // receive-buffer lines other workgroups are still producing (measured: two ranks sharing a GPU, 1 GiB: 2.02 ms
+      // with an agent-scope release here, 1.77 ms without).  tuneFlags 8 puts the agent-scope release back,
+      // 8 + 4 a system-scope one.
+      if (sendMask && (comm->tuneFlags & 8)) {
         if (comm->tuneFlags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         drainVmem();
@@ -872,8 +875,8 @@ __device__ __forceinline__ uint32_t peersMask(int nRanks, int rank) { return ((1
 //             and push it into every peer's window (kind 1)
 //   gather  : copy the n-1 finished pieces that arrive (kind 1) into recvbuff
 template <typename T, int OP>
-__device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks, r = cx.rank;
+__device__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int role) {
+  const int n = cxs[0]->nRanks, r = cxs[0]->rank;
   const Rounds R(w, n);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
@@ -882,10 +885,17 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
   // and where its recvbuff is registered; a reducer that has that registration mapped writes its finished piece
   // straight into the peer's recvbuff and says so with its first broadcast-phase post, and the peer's gather role
   // then has nothing to copy for it.  The words travel beside the FIFO slots, once per launch and channel.
-  const bool words = !cx.comm->netMode;
-  if (role == 0 && cx.tid < n) cx.sh->auxOut[cx.tid] = w.regWord;
-  for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
-    const bool first = g == (size_t)cx.ch;
+  const bool words = !cxs[0]->comm->netMode;
+  if (role == 0 && cxs[0]->tid < n)
+    for (int c = 0; c < nCtx; c++) cxs[c]->sh->auxOut[cxs[c]->tid] = w.regWord;
+  // A workgroup that serves several channels (nCtx > 1: the scatter and gather roles with two ranks, see raCollKernel)
+  // takes their rounds in turn, one step on each.
+  for (size_t k = 0; cxs[0]->ch + k * (size_t)w.nChannels < R.nRounds; k++)
+   for (int c = 0; c < nCtx; c++) {
+    Ctx& cx = *cxs[c];
+    const size_t g = cx.ch + k * (size_t)w.nChannels;
+    if (g >= R.nRounds) continue;
+    const bool first = k == 0;
     if (role == 0) {
       cx.auxSend = words && first;
       cx.step(0, 0, peers, 0, [&]() {
@@ -970,7 +980,7 @@ __device__ void directAllReduce(Ctx& cx, const RaWork& w, int role) {
       });
     }
   }
-  cx.auxRecv = 0; cx.auxSend = 0;
+  for (int c = 0; c < nCtx; c++) { cxs[c]->auxRecv = 0; cxs[c]->auxSend = 0; }
 }
 
 // Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers
@@ -1585,16 +1595,41 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
 }
 
 // ------------------------------------------------------------------ the collective kernel
-// grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.
+// grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.  Exception (w.pairRoles, the all-pairs
+// all-reduce with two ranks): there a reducer moves twice the bytes of a scatter or gather step (two sources and two
+// destinations against one pair), so a scatter or gather workgroup serves TWO channels and all workgroups stay equally
+// busy: nChannels/2 scatter workgroups, nChannels reducers, nChannels/2 gather workgroups.
 template <typename T, int OP>
 __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict__ comm, RaWork w) {
-  __shared__ ChanShared sh;
+  __shared__ ChanShared sh, shB;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
+  if (w.pairRoles) {
+    // all-pairs all-reduce, two ranks
+    const int half = w.nChannels / 2, b = (int)blockIdx.x;
+    Ctx cx;
+    if (b >= half && b < half + w.nChannels) {
+      cx.init(comm, &sh, b - half, w.stepBytes);
+      Ctx* one[1] = {&cx};
+      directAllReduce<T, OP>(one, 1, w, 1);
+      cx.finish(1);
+    } else {
+      const int role = b < half ? 0 : 2;
+      const int ch0 = 2 * (b < half ? b : b - half - w.nChannels);
+      Ctx cxB;
+      cx.init(comm, &sh, ch0, w.stepBytes);
+      cxB.init(comm, &shB, ch0 + 1, w.stepBytes);
+      Ctx* two[2] = {&cx, &cxB};
+      directAllReduce<T, OP>(two, 2, w, role);
+      cx.finish(role);
+      cxB.finish(role);
+    }
+    return;
+  }
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
-  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
   cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
   if (w.algo == RA_ALGO_DIRECT) {
-    if (w.coll == RA_COLL_ALLREDUCE) directAllReduce<T, OP>(cx, w, role);
+    if (w.coll == RA_COLL_ALLREDUCE) { Ctx* one[1] = {&cx}; directAllReduce<T, OP>(one, 1, w, role); }
     else if (w.coll == RA_COLL_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);
     else if (w.coll == RA_COLL_REDUCE) directReduce<T, OP>(cx, w, role);
   } else if (w.algo == RA_ALGO_RING) {
@@ -1605,4 +1640,3 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   }
   cx.finish(role);
 }
-

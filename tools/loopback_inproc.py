@@ -29,7 +29,7 @@ def main():
                  "use bench.py under torch.distributed.run (one process per rank) for more")
     os.environ["RCCL_AMD_MULTI_RANK_GPU"] = "1"
     os.environ.setdefault("RCCL_AMD_SPIN_TIMEOUT_MS", "20000")
-    os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 64 // a.ranks)))
+    os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if a.ranks == 2 else 64) // a.ranks)))
     import torch
     import rccl_amd as ra
     n, count = a.ranks, a.bytes // 4
