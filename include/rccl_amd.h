@@ -236,6 +236,26 @@ ncclResult_t pmscclUnloadAlgo(mscclAlgoHandle_t mscclAlgoHandle);
 ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, size_t count,
                                ncclDataType_t datatype, ncclRedOp_t op, hipStream_t stream);
 
+/* All-reduce that allocates nothing.  It has no counterpart in the reference: it is for callers that cannot
+ * allocate (code under HIP graph capture rules that forbid hipMalloc, tight serving loops, harnesses that forbid
+ * allocation) and therefore cannot create a communicator, whose window ncclCommInitAll / ncclCommInitRank
+ * allocate.  Same arithmetic as ncclAllReduce on a communicator made by ncclCommInitAll(devices): rank r's input
+ * is sendbuffs[r] on devices[r], its result goes to recvbuffs[r] (may equal sendbuffs[r]), contributions are folded
+ * in rank order, so results are bit-identical to ncclAllReduce's.  The kernel of rank r is enqueued on streams[r];
+ * the streams must be distinct when ranks share a device (the n kernels wait for one another).
+ * The staging lines live in a static 8 MiB array that every GPU the library runs on holds until the process ends.
+ * Limits: 1 <= nranks <= 8; count * sizeof(datatype) <= 256 KiB per rank (larger counts return
+ * ncclInvalidArgument: use ncclAllReduce); built-in operators only (ncclSum .. ncclAvg); all ranks in this
+ * process.  Every call on a GPU uses that GPU's one array: two calls whose kernels could run at the same time on
+ * a GPU race, so a call must be ordered (stream order or a synchronisation) after the previous call that
+ * involved any of its GPUs has finished on all of that call's GPUs.  A call is not meant to be replayed from a
+ * captured graph (each call carries a fresh sequence number in its kernel arguments).  The first call that names
+ * a device looks up that device's array (hipGetSymbolAddress) and, between distinct devices, enables peer access;
+ * later calls make no HIP calls besides hipSetDevice and the kernel launches. */
+ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* const* recvbuffs, const int* devices,
+                                     int nranks, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                                     const hipStream_t* streams);
+
 /* Ring schedule synthesis for a single node whose GPUs are joined by direct xGMI links
  * (the job of the ring search + pre-baked models, src/graph/search.cc:919-986,
  * src/graph/rome_models.cc:549-560).  `adj` is an ngpus x ngpus 0/1 matrix of direct links.

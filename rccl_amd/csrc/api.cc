@@ -1,6 +1,7 @@
 // The exported C ABI (include/rccl_amd.h).  Every symbol forwards to an internal function
 // so that calls made inside this library never bind to another RCCL loaded in the process.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "comm.h"
@@ -234,6 +235,48 @@ RA_API ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int ns
   static const int devOps[] = {RA_OP_SUM, RA_OP_PROD, RA_OP_MAX, RA_OP_MIN};
   hipError_t e = raLaunchLocal(dst, srcs, nsrc, -1, false, 0, nullptr, count, datatype, devOps[op], grid, stream);
   if (e != hipSuccess) { RA_WARN("rcclAmdReduceCopy: launch failed: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
+  return ncclSuccess;
+}
+
+
+// No hipMalloc, hipFree or other allocating call on this path: the line buffers are a static array on each GPU
+// (kernels_common.hip), everything else travels in the kernel arguments.
+RA_API ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* const* recvbuffs, const int* devices,
+                                            int nranks, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
+                                            const hipStream_t* streams) {
+  if (!sendbuffs || !recvbuffs || !devices || !streams) { RA_WARN("rcclAmdAllReduceNoAlloc: null argument"); return ncclInvalidArgument; }
+  if (nranks < 1 || nranks > RA_NA_MAX_RANKS) {
+    RA_WARN("rcclAmdAllReduceNoAlloc: %d ranks, 1..%d supported", nranks, RA_NA_MAX_RANKS);
+    return ncclInvalidArgument;
+  }
+  if (datatype < 0 || datatype >= ncclNumTypes || op < 0 || op >= ncclNumOps) {
+    RA_WARN("rcclAmdAllReduceNoAlloc: unsupported type %d / op %d (built-in operators only)", (int)datatype, (int)op);
+    return ncclInvalidArgument;
+  }
+  const size_t bytes = count * raTypeSize(datatype);
+  if (count > RA_NA_MAX_BYTES || bytes > RA_NA_MAX_BYTES) {
+    RA_WARN("rcclAmdAllReduceNoAlloc: %zu elements of %zu bytes exceed the limit of %u bytes per rank; use ncclAllReduce",
+            count, raTypeSize(datatype), RA_NA_MAX_BYTES);
+    return ncclInvalidArgument;
+  }
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess) return ncclUnhandledCudaError;
+  for (int r = 0; r < nranks; r++) {
+    if (devices[r] < 0 || devices[r] >= nDev || devices[r] >= 64) { RA_WARN("rcclAmdAllReduceNoAlloc: rank %d names device %d", r, devices[r]); return ncclInvalidArgument; }
+    if (count && (!sendbuffs[r] || !recvbuffs[r])) { RA_WARN("rcclAmdAllReduceNoAlloc: rank %d has a null buffer", r); return ncclInvalidArgument; }
+  }
+  if (count == 0) return ncclSuccess;
+  int devOp = RA_OP_SUM;
+  uint64_t arg = 0;
+  static const int devOps[] = {RA_OP_SUM, RA_OP_PROD, RA_OP_MAX, RA_OP_MIN};
+  if (op == ncclAvg) RA_CHECK(raAvgOp(nranks, datatype, &devOp, &arg));
+  else devOp = devOps[op];
+  long ms = 120000;                                     // the same knob and default as a communicator's waits
+  if (const char* t = getenv("RCCL_AMD_SPIN_TIMEOUT_MS")) { if (*t) ms = strtol(t, nullptr, 0); }
+  if (ms < 1) ms = 1;
+  hipError_t e = raNoAllocAllReduce(sendbuffs, recvbuffs, devices, nranks, count, datatype, devOp, arg,
+                                    (uint64_t)ms * 100000ull, streams);
+  if (e != hipSuccess) { RA_WARN("rcclAmdAllReduceNoAlloc: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
   return ncclSuccess;
 }
 

@@ -114,3 +114,5 @@ ncclResult_t raGroupEnd();
 int raGroupDepth();
 void raGroupAddInit(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config, int device);
 size_t raTypeSize(int dtype);
+// ncclAvg over n ranks in element type dtype: the device operator and its scalar.
+ncclResult_t raAvgOp(int n, int dtype, int* devOp, uint64_t* arg);

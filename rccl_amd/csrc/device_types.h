@@ -70,6 +70,24 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
 #define RA_LL_GRID 16                  // workgroups of a low-latency launch when ranks share a GPU (8 ranks x 16 stay resident)
 #define RA_LL_MAX_GRID 32              // ... and when every rank has its own GPU; fixed per communicator (each workgroup keeps its own epoch)
 #define RA_LL_THREADS 1024
+
+// The all-reduce that allocates nothing (rcclAmdAllReduceNoAlloc): the one-shot line protocol above with its line
+// buffers in a static array every GPU holds, instead of a communicator's window.
+#define RA_NA_MAX_BYTES (256u << 10)   // largest payload per rank
+#define RA_NA_MAX_RANKS 8
+#define RA_NA_GRID 16
+#define RA_NA_SENDER_BYTES ((size_t)RA_NA_MAX_BYTES * 2)                    // a 16-byte line per 8 payload bytes
+#define RA_NA_SCRATCH_BYTES (2 * RA_NA_MAX_RANKS * RA_NA_SENDER_BYTES)      // two alternating buffers: 8 MiB per GPU
+struct RaNaArgs {
+  char* lines[RA_NA_MAX_RANKS];   // every rank's line array (its GPU's static array)
+  const void* send;
+  void* recv;
+  size_t count;
+  uint64_t opArg;                 // an average's divisor (integers) or 1/n in the element type (floating point)
+  uint64_t timeoutTicks;
+  uint32_t epoch;                 // the same number on every rank of one call, larger than any earlier call's
+  int rank, nRanks;
+};
 // Broadcast and reduce put one presence line per workgroup in the tail of a sender's line buffer; their payloads stay at
 // or below RA_LL_DEFAULT_BYTES, so data lines never reach it.
 #define RA_LL_TOKEN_LINE ((size_t)RA_LL_MAX_BYTES / 8 - RA_LL_MAX_GRID)

@@ -91,6 +91,23 @@ uint8_t f32ToF8Bits(float f, int wm) {
   return (uint8_t)(sign | ((uint32_t)expField << wm) | (uint32_t)mant);
 }
 
+// ncclAvg over n ranks: integers sum and divide, floating point pre-multiplies by 1/n (src/enqueue.cc:1987-2010).
+}  // namespace
+ncclResult_t raAvgOp(int n, int dtype, int* devOp, uint64_t* arg) {
+  switch (dtype) {
+    case ncclInt8: case ncclInt32: case ncclInt64: case ncclUint8: case ncclUint32: case ncclUint64:
+      *devOp = RA_OP_SUMPOSTDIV; *arg = (uint64_t)n; return ncclSuccess;
+    case ncclFloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToF16Bits(float(1.0 / n)); return ncclSuccess;
+    case ncclBfloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToBf16Bits(float(1.0 / n)); return ncclSuccess;
+    case ncclFp8E4M3: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 3); return ncclSuccess;
+    case ncclFp8E5M2: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 2); return ncclSuccess;
+    case ncclFloat32: { float s = float(1.0 / n); uint32_t u; memcpy(&u, &s, 4); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
+    case ncclFloat64: { double s = 1.0 / n; uint64_t u; memcpy(&u, &s, 8); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
+    default: return ncclInvalidArgument;
+  }
+}
+
+namespace {
 // ncclRedOp_t + datatype -> device op and its scalar (src/enqueue.cc:1962-2057).
 ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, uint64_t* arg, const void** argPtr) {
   *arg = 0; *argPtr = nullptr;
@@ -99,20 +116,7 @@ ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, ui
     case ncclProd: *devOp = RA_OP_PROD; return ncclSuccess;
     case ncclMax: *devOp = RA_OP_MAX; return ncclSuccess;
     case ncclMin: *devOp = RA_OP_MIN; return ncclSuccess;
-    case ncclAvg: {
-      const int n = comm->nRanks;
-      switch (dtype) {
-        case ncclInt8: case ncclInt32: case ncclInt64: case ncclUint8: case ncclUint32: case ncclUint64:
-          *devOp = RA_OP_SUMPOSTDIV; *arg = (uint64_t)n; return ncclSuccess;
-        case ncclFloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToF16Bits(float(1.0 / n)); return ncclSuccess;
-        case ncclBfloat16: *devOp = RA_OP_PREMULSUM; *arg = f32ToBf16Bits(float(1.0 / n)); return ncclSuccess;
-        case ncclFp8E4M3: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 3); return ncclSuccess;
-        case ncclFp8E5M2: *devOp = RA_OP_PREMULSUM; *arg = f32ToF8Bits(float(1.0 / n), 2); return ncclSuccess;
-        case ncclFloat32: { float s = float(1.0 / n); uint32_t u; memcpy(&u, &s, 4); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
-        case ncclFloat64: { double s = 1.0 / n; uint64_t u; memcpy(&u, &s, 8); *devOp = RA_OP_PREMULSUM; *arg = u; return ncclSuccess; }
-        default: return ncclInvalidArgument;
-      }
-    }
+    case ncclAvg: return raAvgOp(comm->nRanks, dtype, devOp, arg);
     default: {
       const int ix = op - (int)ncclNumOps;
       if (ix < 0 || ix >= RA_MAX_USER_OPS || !comm->userOps[ix].used) { RA_WARN("invalid reduction operator %d", op); return ncclInvalidArgument; }

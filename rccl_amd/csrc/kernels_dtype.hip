@@ -48,6 +48,11 @@ static hipError_t llOp(const RaDevComm* comm, const RaWork& w, hipStream_t s) {
   return hipGetLastError();
 }
 template <int OP>
+static hipError_t noAllocOp(const RaNaArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((raNoAllocAllReduceKernel<elem_t, OP>), dim3(RA_NA_GRID), dim3(RA_LL_THREADS), 0, s, a);
+  return hipGetLastError();
+}
+template <int OP>
 static hipError_t localOp(const RcArgs& a, size_t nelem, const void* opArgPtr, int grid, hipStream_t s) {
   hipLaunchKernelGGL((raLocalKernel<elem_t, OP>), dim3(grid), dim3(RA_LOCAL_THREADS), 0, s, a, nelem, opArgPtr);
   return hipGetLastError();
@@ -91,6 +96,20 @@ hipError_t RA_CAT(raLaunchLocalDt, RA_DTYPE)(const RcArgs& a, size_t nelem, cons
     case RA_OP_PREMULSUM: return localOp<RA_OP_PREMULSUM>(a, nelem, opArgPtr, grid, s);
 #if RA_IS_INT
     case RA_OP_SUMPOSTDIV: return localOp<RA_OP_SUMPOSTDIV>(a, nelem, opArgPtr, grid, s);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t RA_CAT(raLaunchNoAllocDt, RA_DTYPE)(const RaNaArgs& a, int op, hipStream_t s) {
+  switch (op) {
+    case RA_OP_SUM: return noAllocOp<RA_OP_SUM>(a, s);
+    case RA_OP_PROD: return noAllocOp<RA_OP_PROD>(a, s);
+    case RA_OP_MAX: return noAllocOp<RA_OP_MAX>(a, s);
+    case RA_OP_MIN: return noAllocOp<RA_OP_MIN>(a, s);
+    case RA_OP_PREMULSUM: return noAllocOp<RA_OP_PREMULSUM>(a, s);
+#if RA_IS_INT
+    case RA_OP_SUMPOSTDIV: return noAllocOp<RA_OP_SUMPOSTDIV>(a, s);
 #endif
     default: return hipErrorInvalidValue;
   }

@@ -1594,6 +1594,58 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
 }
 
+// ------------------------------------------------------------------ the all-reduce that allocates nothing
+// Same protocol as raLLAllReduceKernel, all state in the kernel arguments: a.lines[p] is rank p's line array, the
+// lines of sender q for buffer b start at (b * RA_NA_MAX_RANKS + q) * RA_NA_SENDER_BYTES.  Ranks that share a GPU
+// share one array; what sender q stores is the same for every receiver, so they may share q's region too.
+// A wait that outlasts a.timeoutTicks gives up and leaves that thread's outputs unwritten.
+template <typename T, int OP>
+__global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaArgs a) {
+  const int n = a.nRanks, r = a.rank;
+  const uint32_t epoch = a.epoch;
+  const size_t bufOff = (size_t)(epoch & 1u) * RA_NA_MAX_RANKS * RA_NA_SENDER_BYTES;
+  const T* in = (const T*)a.send;
+  T* out = (T*)a.recv;
+  const size_t nUnits = (a.count * sizeof(T) + 7) / 8;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+  for (size_t u = gtid; u < nUnits; u += gsize) {
+    uint64_t v = llLoadUnit<T>(in, u, a.count);
+    if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, a.opArg);
+    u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
+    for (int i = 1; i < n; i++) {
+      const int p = (r + i) % n;
+      stSys((u32x4*)(a.lines[p] + bufOff + (size_t)r * RA_NA_SENDER_BYTES) + u, line);
+    }
+  }
+  bool dead = false;
+  for (size_t u = gtid; u < nUnits; u += gsize) {
+    uint64_t acc = 0;
+    for (int q = 0; q < n; q++) {
+      uint64_t x;
+      if (q == r) {
+        x = llLoadUnit<T>(in, u, a.count);
+        if (OP == RA_OP_PREMULSUM) x = llScale<T, true>(x, a.opArg);
+      } else {
+        const char* lp = a.lines[r] + bufOff + (size_t)q * RA_NA_SENDER_BYTES + u * 16;
+        u32x4 line = llLoadLine(lp);
+        if (!dead && (line.y != epoch || line.w != epoch)) {
+          const uint64_t t0 = wall_clock64();
+          uint32_t spins = 0;
+          do {
+            __builtin_amdgcn_s_sleep(1);
+            line = llLoadLine(lp);
+            if ((++spins & 0xff) == 0 && wall_clock64() - t0 > a.timeoutTicks) { dead = true; break; }
+          } while (line.y != epoch || line.w != epoch);
+        }
+        x = (uint64_t)line.x | ((uint64_t)line.z << 32);
+      }
+      acc = q == 0 ? x : llRed<T, OP>(acc, x);
+    }
+    if (OP == RA_OP_SUMPOSTDIV) acc = llScale<T, false>(acc, a.opArg);
+    if (!dead) llStoreUnit<T>(out, u, a.count, acc);
+  }
+}
+
 // ------------------------------------------------------------------ the collective kernel
 // grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.  Exception (w.pairRoles, the all-pairs
 // all-reduce with two ranks): there a reducer moves twice the bytes of a scatter or gather step (two sources and two
