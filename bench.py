@@ -76,7 +76,7 @@ def main():
         # Loop-back mode (several ranks on one GPU, for kernel work on a one-GPU box): the ranks share
         # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
         # (two ranks: two workgroups per channel, otherwise three)
-        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if n == 2 else 64) // per_gpu)))
+        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if n == 2 else 80) // per_gpu)))
 
     out = sys.stdout
     if n > 1:

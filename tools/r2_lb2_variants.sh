@@ -8,6 +8,7 @@ for l in sys.stdin:
         d=json.loads(l); print(d['ms_per_allreduce'], d['hbm_GBps'], d['exact'], d['plan'], d.get('step_timers'))
     else: print(l[:300])
 "; }
+if [ $# -gt 0 ]; then for v in "$@"; do run $(echo $v | tr ',' ' '); done; exit 0; fi
 run X=1
 run RCCL_AMD_TUNE_FLAGS=8
 run RCCL_AMD_WINDOW_MEM=fine

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-2 profile set: N=1 bench alone and under rocprofv3 (kernel trace), PMC passes for its HBM traffic,
+# 2-rank loop-back (both ranks on one GPU) under rocprofv3 and with step timers.  Results under gpurun_out/r02/.
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out/r02
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout -k 10 300 python3 bench.py > $O/r02_bench_n1.json 2> $O/bench_n1.err || { tail $O/bench_n1.err; exit 1; }
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_n1 -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/r02_bench_n1_under_rocprof.json 2> $O/prof_n1.err || { tail $O/prof_n1.err; exit 1; }
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 200 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_$c.json 2> $O/pmc_$c.err || { tail $O/pmc_$c.err; exit 1; }
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lb2 -- python3 $R/tools/loopback_inproc.py --ranks 2 --iters 20 > $O/r02_loopback_2ranks_1gpu.json 2> $O/prof_lb2.err || { tail $O/prof_lb2.err; exit 1; }
+cd $R
+RCCL_AMD_TUNE_FLAGS=32 timeout -k 10 200 python3 tools/loopback_inproc.py --ranks 2 --iters 20 > $O/r02_loopback_2ranks_1gpu_step_timers.json 2> $O/timers.err || exit 1
+find $O -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
+# keep the merged output small: only the stats and counter files
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*agent_info.csv" -delete
+du -sh $O
