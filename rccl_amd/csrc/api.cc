@@ -212,7 +212,24 @@ RA_API ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype,
 }
 RA_API ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclSend"); }
 RA_API ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclRecv"); }
-RA_API ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) { return outOfScope("ncclCommSplit"); }
+RA_API ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, ncclConfig_t* config) {
+  // src/init.cc:2753-2820
+  RA_CHECK(raCommCheck(comm, "ncclCommSplit"));
+  if (!newcomm) { RA_WARN("ncclCommSplit: newcomm is NULL"); return ncclInvalidArgument; }
+  if (color < 0 && color != NCCL_SPLIT_NOCOLOR) { RA_WARN("ncclCommSplit: invalid colour %d", color); return ncclInvalidArgument; }
+  if (config && (config->magic != 0xcafebeef || config->size < sizeof(size_t) + 2 * sizeof(unsigned))) {
+    RA_WARN("ncclCommSplit: config was not initialised with NCCL_CONFIG_INITIALIZER");
+    return ncclInvalidArgument;
+  }
+  const ncclResult_t ready = raCommPollError(comm);
+  if (ready != ncclSuccess) {
+    RA_WARN("ncclCommSplit: the parent communicator is not ready (%s)", ncclGetErrorString(ready));
+    return ready == ncclInProgress ? ncclInvalidArgument : ready;
+  }
+  *newcomm = NCCL_COMM_NULL;               // stays null until the split has ended
+  if (raGroupDepth() > 0) { raGroupAddSplit(comm, color, key, newcomm, config); return ncclSuccess; }
+  return raCommSplit(comm, color, key, newcomm, config);
+}
 RA_API ncclResult_t ncclGather(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclGather"); }
 RA_API ncclResult_t ncclScatter(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return outOfScope("ncclScatter"); }
 RA_API ncclResult_t ncclAllToAll(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) { return outOfScope("ncclAllToAll"); }

@@ -195,3 +195,8 @@ ncclResult_t RaBootstrap::barrier() { return allGather(nullptr, nullptr, 0); }
 void RaBootstrap::close() {
   if (fd >= 0) { ::close(fd); fd = -1; }
 }
+
+void RaBootstrap::interrupt() {
+  const int f = fd;
+  if (f >= 0) ::shutdown(f, SHUT_RDWR);
+}

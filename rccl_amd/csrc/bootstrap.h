@@ -20,6 +20,8 @@ struct RaBootstrap {
   ncclResult_t allGather(const void* mine, void* all, size_t bytes);
   ncclResult_t barrier();
   void close();
+  // From another thread: makes a connect/allGather that is waiting fail now instead of at its time limit.
+  void interrupt();
 };
 
 // Creates the listening endpoint and its service thread, and writes the id.

@@ -281,6 +281,8 @@ ncclResult_t raCommCheck(const ncclComm* comm, const char* what) {
 }
 
 ncclResult_t raCommPollError(ncclComm* c) {
+  const int init = c->initState.load(std::memory_order_acquire);
+  if (init != ncclSuccess) return (ncclResult_t)init;      // still being set up (ncclInProgress), or the set-up failed
   if (c->asyncError == ncclSuccess && c->hostFlags) {
     const uint32_t e = __atomic_load_n(&c->hostFlags[1], __ATOMIC_RELAXED);
     if (e == RA_ERR_TIMEOUT) {
@@ -391,25 +393,17 @@ uint64_t hostHash() {
 }
 }  // namespace
 
-ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config) {
-  // src/init.cc:2281-2346 (argument checks), 1188-1874 (transport setup)
-  if (!out) { RA_WARN("ncclCommInitRank: comm is NULL"); return ncclInvalidArgument; }
-  if (nranks < 1 || rank < 0 || rank >= nranks) { RA_WARN("ncclCommInitRank: invalid rank %d of %d", rank, nranks); return ncclInvalidArgument; }
-  if (nranks > RA_MAX_RANKS) { RA_WARN("ncclCommInitRank: at most %d ranks per node", RA_MAX_RANKS); return ncclInvalidArgument; }
-  if (config && (config->magic != 0xcafebeef || config->size < sizeof(size_t) + 2 * sizeof(unsigned))) {
-    RA_WARN("ncclCommInitRankConfig: config was not initialised with NCCL_CONFIG_INITIALIZER");
-    return ncclInvalidArgument;
-  }
-  ncclComm* c = new ncclComm;
-  c->rank = rank; c->nRanks = nranks;
-  if (config && config->blocking != NCCL_CONFIG_UNDEF_INT) c->blocking = config->blocking != 0;
+namespace {
+// ncclCommInitRank behind its argument checks: bootstrap, window, peer mappings, device tables.  `c` carries rank,
+// nRanks and device.  On failure the communicator holds no resources any more (the caller still owns the object).
+ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
+  const int nranks = c->nRanks, rank = c->rank;
   ncclResult_t res = ncclSuccess;
   std::vector<PeerInfo> all((size_t)nranks);
   PeerInfo me;
   bool windowOwned = false;      // the clique has taken the window over (it frees it when the last sibling leaves)
   const uint64_t key = raBootstrapKey(id);
   do {
-    if (hipGetDevice(&c->device) != hipSuccess) { res = ncclUnhandledCudaError; break; }
     readTunables(c);
     if (nranks == 1) {
       makeLayout(c);
@@ -513,16 +507,127 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
       (void)hipFree(c->window);      // allocated, never handed to a clique
     }
     c->clique.reset();
-    c->magic = 0;
-    delete c;
-    return res;
+    c->window = nullptr;
+    c->multiProcess = false;
+    for (int p = 0; p < nranks; p++) { c->peerIsIpc[p] = false; c->peerWin[p] = nullptr; }
   }
+  return res;
+}
+
+bool wantsBlocking(const ncclConfig_t* config) {
+  bool blocking = !(config && config->blocking != NCCL_CONFIG_UNDEF_INT && config->blocking == 0);
+  const long env = envLong("NCCL_COMM_BLOCKING", -1);      // overrides the configuration, src/init.cc:2128-2130
+  if (env == 0 || env == 1) blocking = env == 1;
+  return blocking;
+}
+}  // namespace
+
+ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config) {
+  // src/init.cc:2281-2346 (argument checks), 1188-1874 (transport setup)
+  if (!out) { RA_WARN("ncclCommInitRank: comm is NULL"); return ncclInvalidArgument; }
+  if (nranks < 1 || rank < 0 || rank >= nranks) { RA_WARN("ncclCommInitRank: invalid rank %d of %d", rank, nranks); return ncclInvalidArgument; }
+  if (nranks > RA_MAX_RANKS) { RA_WARN("ncclCommInitRank: at most %d ranks per node", RA_MAX_RANKS); return ncclInvalidArgument; }
+  if (config && (config->magic != 0xcafebeef || config->size < sizeof(size_t) + 2 * sizeof(unsigned))) {
+    RA_WARN("ncclCommInitRankConfig: config was not initialised with NCCL_CONFIG_INITIALIZER");
+    return ncclInvalidArgument;
+  }
+  int device = 0;
+  RA_HIP(hipGetDevice(&device));
+  ncclComm* c = new ncclComm;
+  c->rank = rank; c->nRanks = nranks; c->device = device;
+  c->blocking = wantsBlocking(config);
+  if (c->blocking) {
+    const ncclResult_t res = initRankBody(c, id);
+    if (res != ncclSuccess) { c->magic = 0; delete c; return res; }
+    *out = c;
+    return ncclSuccess;
+  }
+  // Non-blocking: the caller gets the handle now and polls ncclCommGetAsyncError, which says ncclInProgress until the
+  // set-up has ended (src/group.cc:412-435).  A failed set-up leaves the handle valid for ncclCommDestroy / Abort.
+  c->initState.store(ncclInProgress, std::memory_order_release);
   *out = c;
+  c->initThread = std::thread([c, id]() {
+    ncclResult_t res = hipSetDevice(c->device) == hipSuccess ? initRankBody(c, id) : ncclUnhandledCudaError;
+    c->initState.store(res, std::memory_order_release);
+  });
+  return ncclInProgress;
+}
+
+// ncclCommSplit (src/init.cc:1909-1960, 2753-2820): ranks that pass the same colour form a new communicator, ordered by
+// key and then by their rank in the parent; NCCL_SPLIT_NOCOLOR takes part in the exchange and gets no communicator.
+// Two all-gathers over the parent (its rendezvous connection, or the in-process exchange of an ncclCommInitAll
+// communicator): colours and keys first, then the ncclUniqueId the first member of every new group has made.
+namespace {
+ncclResult_t commGather(ncclComm* c, const void* mine, void* all, size_t bytes) {
+  if (c->nRanks == 1) { memcpy(all, mine, bytes); return ncclSuccess; }
+  if (c->multiProcess) return c->boot.allGather(mine, all, bytes);
+  return c->clique->gather(c->rank, mine, all, bytes);
+}
+}  // namespace
+
+ncclResult_t RaClique::gather(int rank, const void* mine, void* all, size_t bytes) {
+  std::unique_lock<std::mutex> lk(m);
+  const uint64_t round = xRound;
+  if (xCount == 0) xIn.assign(bytes * (size_t)nRanks, 0);
+  if (xIn.size() != bytes * (size_t)nRanks) { RA_WARN("ranks of one communicator disagree about an exchange"); return ncclInvalidUsage; }
+  memcpy(xIn.data() + (size_t)rank * bytes, mine, bytes);
+  if (++xCount == nRanks) {
+    xOut.swap(xIn);
+    xCount = 0;
+    xRound++;
+    xcv.notify_all();
+  } else if (!xcv.wait_for(lk, std::chrono::seconds(envLong("RCCL_AMD_BOOTSTRAP_TIMEOUT_S", 120)), [&]() { return xRound != round; })) {
+    xCount--;
+    RA_WARN("rank %d waited in vain for the other ranks of its communicator (inside one thread, group the calls)", rank);
+    return ncclRemoteError;
+  }
+  // xOut stays as it is until every rank has come back for the next round, which needs this rank to return first
+  memcpy(all, xOut.data(), bytes * (size_t)nRanks);
   return ncclSuccess;
+}
+
+ncclResult_t raCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* newcomm, const ncclConfig_t* config) {
+  struct Entry { int32_t color, key; };
+  const int n = parent->nRanks;
+  Entry me{color, key};
+  std::vector<Entry> all((size_t)n);
+  RA_CHECK(commGather(parent, &me, all.data(), sizeof me));
+  std::vector<int> members;                 // parent ranks of my group in their new order
+  if (color != NCCL_SPLIT_NOCOLOR)
+    for (int i = 0; i < n; i++) {
+      if (all[(size_t)i].color != color) continue;
+      size_t at = 0;
+      while (at < members.size() && all[(size_t)members[at]].key <= all[(size_t)i].key) at++;
+      members.insert(members.begin() + (long)at, i);
+    }
+  int myRank = 0;
+  for (size_t i = 0; i < members.size(); i++) if (members[i] == parent->rank) myRank = (int)i;
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  ncclResult_t idRes = ncclSuccess;
+  if (members.size() > 1 && members[0] == parent->rank) idRes = raBootstrapCreate(&id);
+  std::vector<ncclUniqueId> ids((size_t)n);
+  RA_CHECK(commGather(parent, &id, ids.data(), sizeof id));    // also when making the id failed: the others are waiting
+  RA_CHECK(idRes);
+  if (color == NCCL_SPLIT_NOCOLOR) {
+    RA_INFO("ncclCommSplit: rank %d passed NCCL_SPLIT_NOCOLOR and gets no communicator", parent->rank);
+    return ncclSuccess;
+  }
+  ncclConfig_t inherited = NCCL_CONFIG_INITIALIZER;           // no config: the child is created like its parent
+  inherited.blocking = parent->blocking ? 1 : 0;
+  DeviceGuard guard;
+  RA_HIP(hipSetDevice(parent->device));
+  RA_INFO("ncclCommSplit: rank %d of %d -> colour %d, rank %d of %zu", parent->rank, n, color, myRank, members.size());
+  return raCommInitRank(newcomm, (int)members.size(), ids[(size_t)members[0]], myRank, config ? config : &inherited);
 }
 
 ncclResult_t raCommDestroy(ncclComm_t c, bool abort) {
   RA_CHECK(raCommCheck(c, abort ? "ncclCommAbort" : "ncclCommDestroy"));
+  if (c->initThread.joinable()) {
+    // a set-up still under way: an abort cuts its rendezvous short, a destroy lets it end
+    if (abort && c->initState.load(std::memory_order_acquire) == ncclInProgress) c->boot.interrupt();
+    c->initThread.join();
+  }
   DeviceGuard guard;
   (void)hipSetDevice(c->device);
   if (abort && c->hostFlags) __atomic_store_n(&c->hostFlags[0], 1u, __ATOMIC_RELAXED);   // spins give up

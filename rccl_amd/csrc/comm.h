@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "bootstrap.h"
@@ -23,6 +26,13 @@ struct RaClique {
   int joined = 0, left = 0;
   std::vector<char*> window;   // per rank, null for ranks of other processes
   std::vector<int> device;
+  // All-gather between the ranks of an ncclCommInitAll communicator (they have no rendezvous connection): every
+  // rank deposits `bytes`, the last one to arrive releases the round.  Used by ncclCommSplit.
+  std::condition_variable xcv;
+  std::vector<char> xIn, xOut;
+  int xCount = 0;
+  uint64_t xRound = 0;
+  ncclResult_t gather(int rank, const void* mine, void* all, size_t bytes);
   ~RaClique();
 };
 
@@ -79,11 +89,17 @@ struct ncclComm {
   ncclResult_t asyncError = ncclSuccess;
   RaUserOp userOps[RA_MAX_USER_OPS];
   bool finalized = false;
+
+  // Non-blocking creation (ncclConfig_t::blocking = 0, src/init.cc:2281-2346, src/group.cc:412-435): the handle is
+  // returned at once, the set-up runs on initThread, and initState is ncclInProgress until it has ended.
+  std::atomic<int> initState{ncclSuccess};
+  std::thread initThread;
 };
 
 // comm.cc
 ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
 ncclResult_t raCommInitRank(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config);
+ncclResult_t raCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm, const ncclConfig_t* config);
 ncclResult_t raCommDestroy(ncclComm_t comm, bool abort);
 ncclResult_t raCommCheck(const ncclComm* comm, const char* what);
 ncclResult_t raCommPollError(ncclComm* comm);
@@ -113,6 +129,7 @@ ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();
 int raGroupDepth();
 void raGroupAddInit(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int rank, const ncclConfig_t* config, int device);
+void raGroupAddSplit(ncclComm_t parent, int color, int key, ncclComm_t* newcomm, const ncclConfig_t* config);
 size_t raTypeSize(int dtype);
 // ncclAvg over n ranks in element type dtype: the device operator and its scalar.
 ncclResult_t raAvgOp(int n, int dtype, int* devOp, uint64_t* arg);

@@ -133,6 +133,7 @@ ncclResult_t translateOp(const ncclComm* comm, int op, int dtype, int* devOp, ui
 // ----- group state (thread-local, src/group.cc:19) -------------------------------------------
 struct InitJob {
   ncclComm_t* out; int nranks; ncclUniqueId id; int rank; ncclConfig_t config; bool haveConfig; int device;
+  ncclComm_t parent; int color, key;      // parent != null: an ncclCommSplit of `parent`
   ncclResult_t result;
 };
 thread_local int tGroupDepth = 0;
@@ -344,6 +345,17 @@ void raGroupAddInit(ncclComm_t* comm, int nranks, const ncclUniqueId& id, int ra
   InitJob j;
   j.out = comm; j.nranks = nranks; j.id = id; j.rank = rank; j.haveConfig = config != nullptr; j.device = device;
   if (config) j.config = *config;
+  j.parent = nullptr; j.color = 0; j.key = 0;
+  j.result = ncclSuccess;
+  tInits.push_back(j);
+}
+
+void raGroupAddSplit(ncclComm_t parent, int color, int key, ncclComm_t* newcomm, const ncclConfig_t* config) {
+  InitJob j;
+  memset(&j.id, 0, sizeof j.id);
+  j.out = newcomm; j.nranks = 0; j.rank = 0; j.haveConfig = config != nullptr; j.device = parent->device;
+  if (config) j.config = *config;
+  j.parent = parent; j.color = color; j.key = key;
   j.result = ncclSuccess;
   tInits.push_back(j);
 }
@@ -362,14 +374,21 @@ ncclResult_t raGroupEnd() {
     for (auto& j : jobs)
       th.emplace_back([&j]() {
         if (hipSetDevice(j.device) != hipSuccess) { j.result = ncclUnhandledCudaError; return; }
-        j.result = raCommInitRank(j.out, j.nranks, j.id, j.rank, j.haveConfig ? &j.config : nullptr);
+        const ncclConfig_t* cfg = j.haveConfig ? &j.config : nullptr;
+        j.result = j.parent ? raCommSplit(j.parent, j.color, j.key, j.out, cfg) : raCommInitRank(j.out, j.nranks, j.id, j.rank, cfg);
       });
     for (auto& t : th) t.join();
-    for (auto& j : jobs) if (j.result != ncclSuccess && res == ncclSuccess) res = j.result;
+    // errors first; otherwise ncclInProgress when a non-blocking communicator is still being set up (src/group.cc:412-435)
+    bool pending = false;
+    for (auto& j : jobs) {
+      if (j.result == ncclInProgress) pending = true;
+      else if (j.result != ncclSuccess && res == ncclSuccess) res = j.result;
+    }
+    if (res == ncclSuccess && pending) res = ncclInProgress;
   }
   std::vector<RaCollArgs> ops;
   ops.swap(tPending);
-  if (res != ncclSuccess) return res;   // an error inside the group cancels its launches
+  if (res != ncclSuccess && res != ncclInProgress) return res;   // an error inside the group cancels its launches
   for (const auto& a : ops) {
     ncclResult_t r = launchOne(a);
     if (r != ncclSuccess && res == ncclSuccess) res = r;
@@ -382,7 +401,10 @@ ncclResult_t raEnqueue(const RaCollArgs& a) {
   ncclResult_t r = checkArgs(a, names[a.coll]);
   if (r == ncclSuccess && a.comm) {
     r = raCommPollError(a.comm);
-    if (r != ncclSuccess) RA_WARN("%s: the communicator has a pending asynchronous error", names[a.coll]);
+    if (r == ncclInProgress) {             // src/init.cc ncclCommEnsureReady
+      RA_WARN("%s: attempt to use the communicator before its creation returned ncclSuccess", names[a.coll]);
+      r = ncclInvalidArgument;
+    } else if (r != ncclSuccess) RA_WARN("%s: the communicator has a pending asynchronous error", names[a.coll]);
   }
   if (r != ncclSuccess) {
     if (tGroupDepth > 0 && tGroupError == ncclSuccess) tGroupError = r;
