@@ -188,9 +188,33 @@ class Communicator:
         else:
             cfg = ncclConfig_t(ctypes.sizeof(ncclConfig_t), 0xcafebeef, 22105, int(blocking), -2**31, -2**31, -2**31,
                                None, -2**31)
-            _check(lib().ncclCommInitRankConfig(ctypes.byref(h), nranks, uid, rank, ctypes.byref(cfg)),
-                   "ncclCommInitRankConfig")
+            rc = lib().ncclCommInitRankConfig(ctypes.byref(h), nranks, uid, rank, ctypes.byref(cfg))
+            if not (rc == ncclInProgress and not blocking):     # non-blocking: poll wait_ready() / async_error()
+                _check(rc, "ncclCommInitRankConfig")
         return cls(h)
+
+    def wait_ready(self, timeout_s=120.0):
+        """Polls ncclCommGetAsyncError until a non-blocking creation has ended (test/common/TestBedChild.cpp:40-55).
+        Returns the number of polls that said ncclInProgress."""
+        import time
+        t0, polls = time.time(), 0
+        while True:
+            st = self.async_error()
+            if st != ncclInProgress:
+                _check(st, "ncclCommGetAsyncError")
+                return polls
+            polls += 1
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("communicator creation still in progress")
+            time.sleep(0.0005)
+
+    def split(self, color, key):
+        """ncclCommSplit: the new communicator, or None for NCCL_SPLIT_NOCOLOR (-1)."""
+        h = ctypes.c_void_p()
+        rc = lib().ncclCommSplit(self.handle, color, key, ctypes.byref(h), None)
+        if rc != ncclInProgress:
+            _check(rc, "ncclCommSplit")
+        return Communicator(h) if h.value else None
 
     @classmethod
     def init_all(cls, ndev, devlist=None):

@@ -508,6 +508,41 @@ def test_host_staged_tcp_transport(bed):
         bed.init_comms({"NCCL_P2P_DISABLE": None, "RCCL_AMD_NCHANNELS": bed.base_env["RCCL_AMD_NCHANNELS"], "NCCL_ALGO": None})
 
 
+def test_comm_split_across_processes(bed):
+    """ncclCommSplit with every rank in its own process (the reference's cases, test/StandaloneTests.cpp:18-153, in its
+    multi-process mode): colours by parity, one colour with reversed keys, upper half NCCL_SPLIT_NOCOLOR.  Every new
+    communicator then runs an all-reduce whose result names exactly its members."""
+    n = bed.nranks
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
+    cases = [([r % 2 for r in range(n)], list(range(n))),
+             ([0] * n, [n - r for r in range(n)]),
+             ([0 if r < n // 2 else -1 for r in range(n)], list(range(n)))]
+    count = 5000
+    for colors, keys in cases:
+        res = bed.split(colors, keys, count)
+        for r in range(n):
+            if colors[r] < 0:
+                assert res[r] is None
+                continue
+            members = sorted((q for q in range(n) if colors[q] == colors[r]), key=lambda q: (keys[q], q))
+            size, new_rank, err, out = res[r]
+            assert (size, new_rank, err) == (len(members), members.index(r), 0), (r, colors, keys, size, new_rank, err)
+            want = len(members) * np.arange(count, dtype=np.int64) + 1000 * sum(members)
+            assert np.array_equal(out.astype(np.int64), want), (r, colors, keys)
+    # the parent is unharmed
+    _check_allreduce(bed, orc.F32, orc.SUM, 70000)
+
+
+def test_non_blocking_creation(bed):
+    """config.blocking = 0 (test/NonBlockingTests.cpp, test/common/TestBedChild.cpp:250-258): ncclCommInitRankConfig
+    returns at once, ncclCommGetAsyncError says ncclInProgress until the creation has ended, and the communicator
+    then behaves like any other."""
+    bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None}, blocking=False)
+    _check_allreduce(bed, orc.F32, orc.SUM, 1048576)
+    _check_allreduce(bed, orc.I32, orc.SUM, 1250)
+    bed.init_comms()
+
+
 def test_missing_peer_is_detected_not_hung():
     """Failure detection (reference: abort flag polled by every device spin, prims_simple.h:82-92, surfaced by
     ncclCommGetAsyncError, init.cc:2842-2849).  A rank that never joins a collective must not hang the others:

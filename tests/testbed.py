@@ -120,13 +120,33 @@ def _child(rank, nranks, device, conn, env):
                 conn.send(("ok", ra.get_unique_id()))
             elif cmd == "init":
                 uid, init_env = args
+                init_env = dict(init_env)
+                blocking = init_env.pop("__blocking__", None)
                 for k, v in init_env.items():
                     if v is None:
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
-                comm = ra.Communicator.init_rank(nranks, uid, rank)
+                comm = ra.Communicator.init_rank(nranks, uid, rank, blocking=blocking)
+                if blocking is False:
+                    comm.wait_ready()
                 conn.send(("ok", (comm.count(), comm.user_rank(), comm.cu_device())))
+            elif cmd == "split":
+                # ncclCommSplit of the bed's communicator, one int32 all-reduce on the new one, then it is destroyed
+                color, key, count = args
+                sub = comm.split(color, key)
+                if sub is None:
+                    conn.send(("ok", None))
+                else:
+                    sub.wait_ready()
+                    src = (torch.arange(count, dtype=torch.int32) + 1000 * rank).cuda()
+                    dst = torch.zeros(count, dtype=torch.int32, device="cuda")
+                    torch.cuda.synchronize()
+                    sub.all_reduce(src, dst, count, ra.ncclInt32, ra.ncclSum, stream)
+                    stream.synchronize()
+                    res = (sub.count(), sub.user_rank(), sub.async_error(), dst.cpu().numpy().tobytes())
+                    sub.destroy()
+                    conn.send(("ok", res))
             elif cmd == "coll" and args.get("skip"):
                 conn.send(("ok", (0, b"")))            # this rank sits the collective out (failure tests)
             elif cmd == "abort":
@@ -538,8 +558,12 @@ class TestBed:
             self.conns[r].send((cmd, args_per_rank[r]))
         return [self._recv(r) for r in range(self.nranks)]
 
-    def init_comms(self, env=None):
-        """(Re)create the communicators; `env` entries are set (None: unset) in every child first."""
+    def init_comms(self, env=None, blocking=None):
+        """(Re)create the communicators; `env` entries are set (None: unset) in every child first.  blocking=False:
+        ncclCommInitRankConfig with config.blocking = 0, then ncclCommGetAsyncError until the creation has ended."""
+        if blocking is not None:
+            env = dict(env or {})
+            env["__blocking__"] = blocking
         self.destroy_comms()
         if len(self.answered) < self.nranks:
             self._all("ping", [None] * self.nranks)      # every child is past its imports before any rank waits for the others
@@ -607,6 +631,14 @@ class TestBed:
         for r, (errs, _) in enumerate(res):
             assert errs == (0, 0), f"rank {r}: asynchronous errors {errs}"
         return [[np.frombuffer(b, dtype=np.uint8) for b in outs] for _, outs in res]
+
+    def split(self, colors, keys, count=4096):
+        """ncclCommSplit on every rank (colour -1: NCCL_SPLIT_NOCOLOR), then an int32 all-reduce of rank * 1000 + i on each
+        new communicator.  Returns per rank None or (new size, new rank, async error, result as int32 array)."""
+        if not self.inited:
+            self.init_comms()
+        res = self._all("split", [(colors[r], keys[r], count) for r in range(self.nranks)])
+        return [None if x is None else (x[0], x[1], x[2], np.frombuffer(x[3], dtype=np.int32)) for x in res]
 
     def command(self, rank, cmd, args=None):
         self.conns[rank].send((cmd, args))
