@@ -74,6 +74,16 @@ void readTunables(ncclComm* c) {
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
+  // One-exchange all-reduce (enqueue.cc, proto 2): it sends (n-1) x S per rank instead of 2(n-1)/n x S, so the default
+  // limit follows the group size: with two ranks the link bytes are the same and only HBM traffic grows (5 S against
+  // 4 S per rank), with four they double, with eight they are four times as many.
+  {
+    const long dflt = c->nRanks == 2 ? (32L << 20) : c->nRanks <= 4 ? (4L << 20) : (1L << 20);
+    long v = envLong("RCCL_AMD_ONESHOT_MAX_BYTES", dflt);
+    const long most = (256L << 20) / c->nRanks;        // two buffers for every sender: at most 512 MiB of window
+    if (v > most) { RA_INFO("RCCL_AMD_ONESHOT_MAX_BYTES=%ld reduced to %ld (window space)", v, most); v = most; }
+    c->oneShotMaxBytes = v > 0 ? (size_t)v : 0;
+  }
   // NCCL_PROTO (src/graph/tuning.cc:476-485): "Simple" keeps small all-reduces off the low-latency path
   const char* pr = getenv("NCCL_PROTO");
   c->allowLL = !(pr && *pr && !strcasestr(pr, "LL"));
@@ -110,7 +120,10 @@ void makeLayout(ncclComm* c) {
   l.dataOffset = alignUp(raFlagBytes(l), 4096);
   l.llOffset = alignUp(raDataOffset(l, l.nChannels, 0, 0), 4096);   // one past the last FIFO
   l.llBytes = (size_t)RA_LL_MAX_BYTES * 2;                          // 16-byte line per 8 bytes of payload
-  l.totalBytes = raLLOffset(l, 2, 0);
+  l.osFlagOffset = alignUp(raLLOffset(l, 2, 0), 4096);
+  l.osBytes = staged ? 0 : alignUp(c->oneShotMaxBytes, 4096);
+  l.osDataOffset = l.osFlagOffset + (l.osBytes ? alignUp((size_t)2 * RA_OS_MAX_GRID * l.nRanks * RA_FLAG_STRIDE, 4096) : 0);
+  l.totalBytes = raOsDataOffset(l, 2, 0);
 }
 
 // Low-latency launches use 32 workgroups when every rank has a GPU to itself and 16 when ranks share one (8 ranks x 16
@@ -120,6 +133,12 @@ void setLLGrid(ncclComm* c, bool shared) {
   if (g < 1) g = 1;
   if (g > RA_LL_MAX_GRID) g = RA_LL_MAX_GRID;
   c->llGrid = (int)g;
+  // One-exchange launches: a workgroup that waits for its peer keeps its compute unit, so when ranks share a GPU all of
+  // their workgroups must fit it together (128 in all); a rank with a GPU to itself uses 128.
+  long og = envLong("RCCL_AMD_ONESHOT_GRID", shared ? 128 / c->nRanks : 128);
+  if (og < 1) og = 1;
+  if (og > RA_OS_MAX_GRID) og = RA_OS_MAX_GRID;
+  c->osGrid = (int)og;
 }
 
 uint64_t busIdOf(int device) {
@@ -148,7 +167,7 @@ ncclResult_t allocWindow(ncclComm* c) {
   (void)hipGetLastError();
   c->window = (char*)p;
   RA_HIP(hipMemset(p, 0, c->lay.dataOffset));   // all flag words start at zero
-  RA_HIP(hipMemset((char*)p + c->lay.llOffset, 0, c->lay.totalBytes - c->lay.llOffset));   // no line carries a live epoch
+  RA_HIP(hipMemset((char*)p + c->lay.llOffset, 0, c->lay.osDataOffset - c->lay.llOffset));   // no line carries a live epoch, no flag is up
   RA_HIP(hipDeviceSynchronize());
   RA_INFO("rank %d: window %p, %zu MiB (%d channels x %d ranks x %d kinds x %d slots x %u KiB)", c->rank, p,
           c->lay.totalBytes >> 20, c->lay.nChannels, c->nRanks, RA_NKINDS, c->lay.nSlots, c->lay.slotBytes >> 10);
@@ -177,6 +196,8 @@ ncclResult_t buildDevComm(ncclComm* c) {
   RA_HIP(hipMemset(c->steps, 0, 2 * nSteps * sizeof(uint64_t)));
   RA_HIP(hipMalloc((void**)&c->llEpoch, RA_LL_MAX_GRID * sizeof(uint32_t)));
   RA_HIP(hipMemset(c->llEpoch, 0, RA_LL_MAX_GRID * sizeof(uint32_t)));
+  RA_HIP(hipMalloc((void**)&c->osEpoch, RA_OS_MAX_GRID * sizeof(uint64_t)));
+  RA_HIP(hipMemset(c->osEpoch, 0, RA_OS_MAX_GRID * sizeof(uint64_t)));
   RA_HIP(hipMalloc((void**)&c->regTable, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
   RA_HIP(hipMemset(c->regTable, 0, sizeof(RaRegSlot) * RA_MAX_RANKS * RA_MAX_REGS));
   RA_HIP(hipMalloc((void**)&c->stats, 32 * sizeof(uint64_t)));
@@ -196,6 +217,7 @@ ncclResult_t buildDevComm(ncclComm* c) {
   h.sendStep = c->steps;
   h.recvStep = c->steps + nSteps;
   h.llEpoch = c->llEpoch;
+  h.osEpoch = c->osEpoch;
   h.abortFlag = c->hostFlagsDev;
   h.errorFlag = c->hostFlagsDev + 1;
   // wall_clock64() ticks at 100 MHz on gfx950
@@ -253,6 +275,8 @@ void freeLocal(ncclComm* c) {
   if (c->devComm) (void)hipFree(c->devComm);
   if (c->steps) (void)hipFree(c->steps);
   if (c->llEpoch) (void)hipFree(c->llEpoch);
+  if (c->osEpoch) (void)hipFree(c->osEpoch);
+  c->osEpoch = nullptr;
   if (c->regTable) (void)hipFree(c->regTable);
   if (c->stats) (void)hipFree(c->stats);
   c->llEpoch = nullptr; c->regTable = nullptr; c->stats = nullptr;
@@ -378,6 +402,7 @@ namespace {
 struct PeerInfo {            // one per rank, all-gathered at init (cf. src/include/transport.h:36-50)
   int32_t rank, pid, device, maxChannels;
   uint32_t slotBytes; int32_t nSlots;
+  uint64_t osBytes;
   uint64_t hostHash;
   uint64_t busId;            // hash of the device's PCI bus id: equal on two ranks = they share a GPU
   uint64_t windowPtr;        // meaningful inside the owner's process only
@@ -436,7 +461,7 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
     if ((res = allocWindow(c)) != ncclSuccess) break;
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
-    me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.hostHash = hostHash(); me.busId = busIdOf(c->device);
+    me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.osBytes = c->lay.osBytes; me.hostHash = hostHash(); me.busId = busIdOf(c->device);
     me.windowPtr = (uint64_t)(uintptr_t)c->window;
     me.haveHandle = hipIpcGetMemHandle(&me.handle, c->window) == hipSuccess;
     (void)hipGetLastError();
@@ -462,7 +487,7 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
     for (int p = 0; p < nranks && res == ncclSuccess; p++) {
       const PeerInfo& pi = all[(size_t)p];
       if (pi.hostHash != me.hostHash) { RA_WARN("rank %d is on another host: only one node is supported", p); res = ncclInvalidUsage; break; }
-      if (pi.maxChannels != me.maxChannels || pi.slotBytes != me.slotBytes || pi.nSlots != me.nSlots) {
+      if (pi.maxChannels != me.maxChannels || pi.slotBytes != me.slotBytes || pi.nSlots != me.nSlots || pi.osBytes != me.osBytes) {
         RA_WARN("rank %d uses different channel/slot settings (%d ch, %u B, %d slots) than rank %d (%d, %u, %d)", p,
                 pi.maxChannels, pi.slotBytes, pi.nSlots, rank, me.maxChannels, me.slotBytes, me.nSlots);
         res = ncclInvalidUsage; break;

@@ -58,6 +58,7 @@ struct ncclComm {
   bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol
   int llGrid = RA_LL_GRID;   // workgroups of a low-latency launch (the same on every rank of the communicator)
   size_t minChunkBytes = 32 << 10;
+  size_t oneShotMaxBytes = 0;  // all-reduces up to this size (and above the low-latency limit) run as one exchange
 
   // device resources
   RaWindowLayout lay{};
@@ -67,6 +68,8 @@ struct ncclComm {
   RaDevComm* devComm = nullptr;
   uint64_t* steps = nullptr;         // sendStep + recvStep
   uint32_t* llEpoch = nullptr;       // per low-latency workgroup launch counters (device)
+  uint64_t* osEpoch = nullptr;       // per one-exchange workgroup launch counters (device)
+  int osGrid = 64;                   // workgroups of a one-exchange launch (the same on every rank)
   uint32_t* hostFlags = nullptr;     // pinned, mapped: [0] abort request, [1] device error
   uint32_t* hostFlagsDev = nullptr;
   RaRegSlot* regTable = nullptr;     // device copy of the peers' registered allocations as mapped here
@@ -108,6 +111,7 @@ ncclResult_t raCommPollError(ncclComm* comm);
 struct RaPlan {
   int algo, proto, nChannels, grid, block;
   int pairRoles;             // RaWork::pairRoles
+  int oneShot;               // RaWork::oneShot (proto 2)
   size_t chunkElems, lastChunkElems;
 };
 struct RaCollArgs {
@@ -123,7 +127,7 @@ struct RaCollArgs {
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
 ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, bool allowLL, RaPlan* plan);
+                       size_t minChunkBytes, int blockThreads, bool allowLL, size_t oneShotMaxBytes, RaPlan* plan);
 ncclResult_t raEnqueue(const RaCollArgs& a);
 ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();

@@ -45,6 +45,11 @@ struct RaWindowLayout {
   size_t dataOffset;  // start of the slot storage inside the window
   size_t llOffset;    // start of the low-latency line buffers (2 buffers x nRanks senders)
   size_t llBytes;     // bytes of one sender's line buffer (16 B per 8 B of payload)
+  // One-exchange all-reduce (mid-size payloads): plain 16-byte packs, 2 buffers x nRanks senders x osBytes, and one
+  // flag line per (buffer, workgroup, sender) in front of them.  osBytes 0: not available.
+  size_t osFlagOffset;
+  size_t osDataOffset;
+  size_t osBytes;     // payload one sender's region has room for
   size_t totalBytes;
 };
 
@@ -70,6 +75,15 @@ __host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, 
 #define RA_LL_GRID 16                  // workgroups of a low-latency launch when ranks share a GPU (8 ranks x 16 stay resident)
 #define RA_LL_MAX_GRID 32              // ... and when every rank has its own GPU; fixed per communicator (each workgroup keeps its own epoch)
 #define RA_LL_THREADS 1024
+
+// One-exchange all-reduce: workgroups of a launch (fixed per communicator, every rank the same), 1024 threads each.
+#define RA_OS_MAX_GRID 128
+__host__ __device__ inline size_t raOsFlagOffset(const RaWindowLayout& l, int buf, int wg, int sender) {
+  return l.osFlagOffset + (((size_t)buf * RA_OS_MAX_GRID + wg) * l.nRanks + sender) * RA_FLAG_STRIDE;
+}
+__host__ __device__ inline size_t raOsDataOffset(const RaWindowLayout& l, int buf, int sender) {
+  return l.osDataOffset + ((size_t)buf * l.nRanks + sender) * l.osBytes;
+}
 
 // The all-reduce that allocates nothing (rcclAmdAllReduceNoAlloc): the one-shot line protocol above with its line
 // buffers in a static array every GPU holds, instead of a communicator's window.
@@ -119,6 +133,7 @@ struct RaDevComm {
   uint64_t* sendStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has published
   uint64_t* recvStep;         // [nChannels][nRanks][RA_NKINDS] slots this rank has consumed
   uint32_t* llEpoch;          // [RA_LL_MAX_GRID] launches each low-latency workgroup has run
+  uint64_t* osEpoch;          // [RA_OS_MAX_GRID] one-exchange launches each workgroup has run
   uint32_t* abortFlag;        // host-mapped; non-zero asks every spin to give up
   uint32_t* errorFlag;        // host-mapped; first device error code
   uint64_t timeoutTicks;      // per-wait limit in 100 MHz wall-clock ticks
@@ -147,6 +162,8 @@ struct RaWork {
   uint32_t stepBytes;  // bytes one FIFO slot carries in this launch (chunkElems * elemSize)
   int root;            // broadcast / reduce
   int pairRoles;       // all-pairs all-reduce: scatter and gather workgroups serve two channels each (see raCollKernel)
+  int oneShot;         // all-reduce in one exchange: every rank sends its whole input to every peer and folds all n
+                       // contributions itself (raOneShotKernel)
   uint64_t regWord;    // announce word for recv (0: not registered)
   int peerRegs;        // some peer registration is mapped on this rank: read the peers' announce words
 };

@@ -194,6 +194,7 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.stepBytes = (uint32_t)(p.chunkElems * es);
   w.root = a.root;
   w.pairRoles = p.pairRoles;
+  w.oneShot = p.oneShot;
   if (a.coll == RA_COLL_ALLREDUCE && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net)
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
   if (a.coll == RA_COLL_ALLGATHER && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net && a.count * es >= RA_AG_ANNOUNCE_BYTES)
@@ -243,7 +244,7 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
 // (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
 // and NCCL_ALGO selects the ring or chain schedules.
 ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, bool allowLL, RaPlan* p) {
+                       size_t minChunkBytes, int blockThreads, bool allowLL, size_t oneShotMaxBytes, RaPlan* p) {
   const size_t es = raTypeSize(dtype);
   if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
   int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
@@ -252,6 +253,7 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   if (algo == RA_ALGO_DIRECT && n > RA_MAX_SRCS) algo = RA_ALGO_RING;
   p->algo = algo;
   p->proto = 0;
+  p->oneShot = 0;
   p->block = blockThreads;
   const size_t unit = 16 / es;                                  // elements per 16-byte pack
   const size_t maxChunk = slotBytes / es / unit * unit;         // one FIFO slot
@@ -323,14 +325,30 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
     p->nChannels = RA_LL_GRID;
     p->grid = RA_LL_GRID;
     p->block = RA_LL_THREADS;
+    return ncclSuccess;
+  }
+  // Mid-size all-reduces on the all-pairs schedule run as ONE exchange (proto 2): every rank pushes its whole input
+  // into every peer's window and folds the n contributions itself, in rank order.  The three flag-synchronised phases
+  // of the FIFO schedule become one push and one fold, for (n-1) x S link bytes per rank instead of 2(n-1)/n x S:
+  // the same bytes with two ranks, twice as many with four, so the limit shrinks as the group grows (comm.cc).
+  if (coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && n > 1 && n <= RA_MAX_SRCS && count * es <= oneShotMaxBytes) {
+    p->proto = 2;
+    p->oneShot = 1;
+    p->pairRoles = 0;
+    p->nChannels = 64;
+    p->grid = 64;
+    p->block = 1024;
+    p->chunkElems = count;
+    p->lastChunkElems = count;
   }
   return ncclSuccess;
 }
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
   RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
-                     c->blockThreads, c->allowLL && !c->net, p));
+                     c->blockThreads, c->allowLL && !c->net, c->lay.osBytes ? c->oneShotMaxBytes : 0, p));
   if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }
+  if (p->proto == 2) { p->nChannels = c->osGrid; p->grid = c->osGrid; }
   return ncclSuccess;
 }
 

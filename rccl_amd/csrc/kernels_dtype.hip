@@ -39,7 +39,8 @@ typedef f8e5m2_t elem_t;
 
 template <int OP>
 static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int block, hipStream_t s) {
-  hipLaunchKernelGGL((raCollKernel<elem_t, OP>), dim3(grid), dim3(block), 0, s, comm, w);
+  if (w.oneShot) hipLaunchKernelGGL((raOneShotKernel<elem_t, OP>), dim3(grid), dim3(1024), 0, s, comm, w);
+  else hipLaunchKernelGGL((raCollKernel<elem_t, OP>), dim3(grid), dim3(block), 0, s, comm, w);
   return hipGetLastError();
 }
 template <int OP>

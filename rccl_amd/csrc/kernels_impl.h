@@ -676,6 +676,28 @@ __device__ __forceinline__ void stFlag(uint64_t* p, uint64_t v) {
 }
 __device__ __forceinline__ void drainVmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Waits until *f >= want.  Every wait is bounded and watches the communicator's abort request; once one has given up
+// (*aborted, a flag of the workgroup), the later ones return at once.
+static __device__ __forceinline__ void raSpin(const RaDevComm* comm, int* aborted, const uint64_t* f, uint64_t want) {
+  if (*aborted) return;
+  const uint64_t t0 = wall_clock64();
+  uint32_t spins = 0;
+  while (ldFlag(f) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 0x3ff) == 0) {
+      const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+      const bool late = wall_clock64() - t0 > comm->timeoutTicks;
+      if (asked || late || *aborted) {
+        *aborted = 1;
+        uint32_t expect = RA_ERR_NONE;
+        __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
+                                             __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+      }
+    }
+  }
+}
+
 struct ChanShared {
   uint64_t sendStep[RA_MAX_RANKS][RA_NKINDS];
   uint64_t recvStep[RA_MAX_RANKS][RA_NKINDS];
@@ -744,25 +766,7 @@ struct Ctx {
     }
   }
 
-  __device__ void spin(const uint64_t* f, uint64_t want) {
-    if (sh->aborted) return;
-    const uint64_t t0 = wall_clock64();
-    uint32_t spins = 0;
-    while (ldFlag(f) < want) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 0x3ff) == 0) {
-        const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-        const bool late = wall_clock64() - t0 > comm->timeoutTicks;
-        if (asked || late || sh->aborted) {
-          sh->aborted = 1;
-          uint32_t expect = RA_ERR_NONE;
-          __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
-                                               __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          return;
-        }
-      }
-    }
-  }
+  __device__ void spin(const uint64_t* f, uint64_t want) { raSpin(comm, &sh->aborted, f, want); }
 
   // One protocol step.  recvMask/sendMask: bit p set = peer p takes part.  Lane p of wave 0
   // waits for peer p's data (tail), lane 16+p waits for a free slot towards peer p (head).
@@ -1644,6 +1648,71 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaAr
     if (OP == RA_OP_SUMPOSTDIV) acc = llScale<T, false>(acc, a.opArg);
     if (!dead) llStoreUnit<T>(out, u, a.count, acc);
   }
+}
+
+// ------------------------------------------------------------------ all-reduce in one exchange (mid-size payloads)
+// Every rank pushes its whole input into every peer's window and folds the n contributions itself, in rank order, so
+// all ranks end with the same bits as the all-pairs schedule gives.  Workgroup b of every rank owns the same slice of
+// the payload (whole 16-byte packs; the last one with work also takes the sub-pack tail): it pushes the slice (plain
+// packs, write-through), raises one flag per peer, waits for the peers' flags of the same slice and folds.  Nothing
+// is waited for before the push: two buffers alternate by launch parity, and a rank cannot get two launches ahead of a
+// peer because finishing a launch needs that peer's flags of the launch (the flow control of the low-latency kernel).
+// Every workgroup counts every launch (with or without work), so all of them agree on the parity.
+// In place: a slice is overwritten by the workgroup that pushed it, after its push.
+template <typename T, int OP>
+__global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  __shared__ int aborted;
+  RcArgs rc;
+  const int n = comm->nRanks, r = comm->rank, tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
+  const uint64_t epoch = comm->osEpoch[b] + 1;
+  const int buf = (int)(epoch & 1u);
+  constexpr size_t EPP = 16 / sizeof(T);
+  const size_t npacks = w.count / EPP;
+  size_t per = (npacks + gridDim.x - 1) / gridDim.x;
+  per = (per + 63) / 64 * 64;                      // whole 1 KiB rows
+  if (per == 0) per = 64;
+  const size_t last = npacks == 0 ? 0 : (npacks - 1) / per;       // the workgroup that also owns the tail
+  size_t e0 = 0, ne = 0;
+  if ((size_t)b <= last) {
+    const size_t p0 = (size_t)b * per, p1 = p0 + per < npacks ? p0 + per : npacks;
+    e0 = p0 * EPP;
+    ne = ((size_t)b == last ? w.count : p1 * EPP) - e0;
+  }
+  const T* in = (const T*)w.send + e0;
+  T* out = (T*)w.recv + e0;
+  const size_t boff = e0 * sizeof(T);
+  if (tid == 0) aborted = 0;
+  if (ne) {
+    // 1. my slice to everyone
+    rc.ns = 1; rc.nd = n - 1; rc.preIdx = 0; rc.post = false; rc.nLocal = 0; rc.opArg = w.opArg;
+    rc.src[0] = (const char*)in;
+    for (int i = 0; i < n - 1; i++) {
+      const int p = (r + 1 + (i + b) % (n - 1)) % n;            // workgroups start on different links
+      rc.dst[i] = comm->win[p] + raOsDataOffset(comm->lay, buf, r) + boff;
+    }
+    __syncthreads();                               // `aborted` is initialised
+    if (OP == RA_OP_PREMULSUM) rcWG<T, OP>(rc, ne, tid, nthr);
+    else copyWG(rc, ne * sizeof(T), tid, nthr);
+    drainVmem();                                   // every wave: its stores are at their destination
+    __syncthreads();
+    if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), epoch);
+    // 2. the peers' slices
+    if (tid < n && tid != r) {
+      raSpin(comm, &aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), epoch);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    rc.ns = n; rc.nd = 1; rc.preIdx = r; rc.post = true; rc.nLocal = 1;
+    for (int j = 0; j < n; j++)
+      rc.src[j] = j == r ? (const char*)in : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
+    rc.dst[0] = (char*)out;
+    if (tid < 64) drainVmem();
+    __syncthreads();
+    // 3. the fold, in rank order
+    if (!aborted) rcWG<T, OP>(rc, ne, tid, nthr);
+  }
+  __syncthreads();
+  if (tid == 0) comm->osEpoch[b] = epoch;
 }
 
 // ------------------------------------------------------------------ the collective kernel
