@@ -4,6 +4,7 @@
 #include <errno.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <string.h>
 #include <sys/socket.h>
 #include <sys/time.h>
@@ -47,6 +48,24 @@ bool recvAll(int fd, void* p, size_t n) {
   while (n) {
     ssize_t k = ::recv(fd, c, n, 0);
     if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; }
+    c += k; n -= (size_t)k;
+  }
+  return true;
+}
+
+int timeoutSeconds();
+// A rank's receive: in slices of 100 ms so that RaBootstrap::interrupt() ends it, `limitS` seconds in all (0: no limit).
+bool recvWatched(int fd, void* p, size_t n, const std::atomic<bool>& cancelled, int limitS) {
+  char* c = (char*)p;
+  int waitedMs = 0;
+  while (n) {
+    if (cancelled.load(std::memory_order_relaxed)) { errno = ECANCELED; return false; }
+    struct pollfd pf; pf.fd = fd; pf.events = POLLIN; pf.revents = 0;
+    const int r = ::poll(&pf, 1, 100);
+    if (r < 0) { if (errno == EINTR) continue; return false; }
+    if (r == 0) { waitedMs += 100; if (limitS > 0 && waitedMs >= limitS * 1000) { errno = ETIMEDOUT; return false; } continue; }
+    const ssize_t k = ::recv(fd, c, n, 0);
+    if (k <= 0) { if (k < 0 && (errno == EINTR || errno == EAGAIN)) continue; return false; }
     c += k; n -= (size_t)k;
   }
   return true;
@@ -162,6 +181,7 @@ ncclResult_t RaBootstrap::connect(const ncclUniqueId& id, int rank_, int nRanks_
   IdPayload p; memcpy(&p, id.internal, sizeof p);
   if (p.magic != kMagic) { RA_WARN("bootstrap: the ncclUniqueId was not produced by ncclGetUniqueId"); return ncclInvalidArgument; }
   rank = rank_; nRanks = nRanks_;
+  if (cancelled.load()) return ncclSystemError;
   fd = ::socket(AF_INET, SOCK_STREAM, 0);
   if (fd < 0) return ncclSystemError;
   setTimeouts(fd);
@@ -169,7 +189,7 @@ ncclResult_t RaBootstrap::connect(const ncclUniqueId& id, int rank_, int nRanks_
   sa.sin_family = AF_INET; sa.sin_addr.s_addr = p.addr; sa.sin_port = p.port;
   int tries = 0;
   while (::connect(fd, (struct sockaddr*)&sa, sizeof sa)) {
-    if ((errno == ECONNREFUSED || errno == EINTR) && ++tries < 200) { usleep(50000); continue; }
+    if ((errno == ECONNREFUSED || errno == EINTR) && ++tries < 200 && !cancelled.load()) { usleep(50000); continue; }
     RA_WARN("bootstrap: connect failed: %s", strerror(errno));
     close();
     return ncclSystemError;
@@ -182,8 +202,9 @@ ncclResult_t RaBootstrap::connect(const ncclUniqueId& id, int rank_, int nRanks_
 ncclResult_t RaBootstrap::allGather(const void* mine, void* all, size_t bytes) {
   if (fd < 0) return ncclInternalError;
   uint64_t len = bytes, back = 0;
-  if (!sendAll(fd, &len, sizeof len) || (bytes && !sendAll(fd, mine, bytes)) || !recvAll(fd, &back, sizeof back) ||
-      back != len || (bytes && !recvAll(fd, all, bytes * (size_t)nRanks))) {
+  const int limit = timeoutSeconds();
+  if (!sendAll(fd, &len, sizeof len) || (bytes && !sendAll(fd, mine, bytes)) || !recvWatched(fd, &back, sizeof back, cancelled, limit) ||
+      back != len || (bytes && !recvWatched(fd, all, bytes * (size_t)nRanks, cancelled, limit))) {
     RA_WARN("bootstrap: exchange with the other ranks failed (rank %d of %d): %s", rank, nRanks, strerror(errno));
     return ncclRemoteError;
   }
@@ -197,6 +218,7 @@ void RaBootstrap::close() {
 }
 
 void RaBootstrap::interrupt() {
+  cancelled.store(true);
   const int f = fd;
   if (f >= 0) ::shutdown(f, SHUT_RDWR);
 }

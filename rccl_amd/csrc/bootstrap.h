@@ -7,12 +7,14 @@
 // runs a small service thread that gathers one blob per rank and returns the
 // concatenation to everyone.
 #pragma once
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 #include "rccl_amd.h"
 
 struct RaBootstrap {
   int fd = -1;
+  std::atomic<bool> cancelled{false};   // set by interrupt(): every wait of this connection gives up
   int rank = 0, nRanks = 0;
   // Connect to the endpoint encoded in `id`.  Blocks until all nRanks have joined.
   ncclResult_t connect(const ncclUniqueId& id, int rank_, int nRanks_);

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <unistd.h>
+#include <chrono>
 #include <vector>
 #include "rccl_amd.h"
 
@@ -229,16 +230,23 @@ static int nonBlocking() {
   return 0;
 }
 
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main() {
+  const double t0 = now();
   setenv("RCCL_AMD_MULTI_RANK_GPU", "1", 1);
   setenv("RCCL_AMD_NCHANNELS", "16", 0);
   setenv("RCCL_AMD_SPIN_TIMEOUT_MS", "20000", 0);
   HIPCHECK(hipSetDevice(0));
   if (groupLaunchFour(1250)) return 1;            // one-shot low-latency protocol
+  printf("[%.1f s]\n", now() - t0);
   if (groupLaunchFour(3 * 1048576 + 1000)) return 1;   // FIFO protocol, ragged
-  for (int mode = 0; mode < 3; mode++) if (splitCase(mode)) return 1;
+  printf("[%.1f s]\n", now() - t0);
+  for (int mode = 0; mode < 3; mode++) { if (splitCase(mode)) return 1; printf("[%.1f s]\n", now() - t0); }
   if (splitByKey()) return 1;
+  printf("[%.1f s]\n", now() - t0);
   if (nonBlocking()) return 1;
+  printf("[%.1f s]\n", now() - t0);
   printf("multi-communicator test passed\n");
   return 0;
 }
