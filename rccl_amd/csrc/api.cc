@@ -315,7 +315,7 @@ RA_API ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncc
                                          size_t* chunkElems, size_t* lastChunkElems, int* grid) {
   if (coll < 0 || coll > RA_COLL_ALLGATHER) return ncclInvalidArgument;
   RaPlan p;
-  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, maxChannels, slotBytes, minChunkBytes, 1024, false, 0, &p));
+  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, maxChannels, slotBytes, minChunkBytes, 1024, 0, 0, &p));
   if (algoOut) *algoOut = p.algo;
   if (nChannels) *nChannels = p.nChannels;
   if (chunkElems) *chunkElems = p.chunkElems;

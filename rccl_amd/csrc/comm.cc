@@ -76,9 +76,13 @@ void readTunables(ncclComm* c) {
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
   // One-exchange all-reduce (enqueue.cc, proto 2): it sends (n-1) x S per rank instead of 2(n-1)/n x S, so the default
   // limit follows the group size: with two ranks the link bytes are the same and only HBM traffic grows (5 S against
-  // 4 S per rank), with four they double, with eight they are four times as many.
+  // 4 S per rank), with four they double, with eight they are four times as many.  Priced against one xGMI link per
+  // peer (about 120 GB/s achievable) and the roughly 30 us the two extra flag-synchronised phases of the three-phase
+  // schedule cost, the break-even is near 7 MB at four ranks and 5 MB at eight; the defaults stay below that (4 MiB,
+  // 2 MiB).  With ranks sharing one GPU (no links, HBM only) one exchange measured faster up to 16 MiB at four ranks
+  // and 8 MiB at eight (tools/oneshot_limits.sh).
   {
-    const long dflt = c->nRanks == 2 ? (32L << 20) : c->nRanks <= 4 ? (4L << 20) : (1L << 20);
+    const long dflt = c->nRanks == 2 ? (64L << 20) : c->nRanks <= 4 ? (4L << 20) : (2L << 20);
     long v = envLong("RCCL_AMD_ONESHOT_MAX_BYTES", dflt);
     const long most = (256L << 20) / c->nRanks;        // two buffers for every sender: at most 512 MiB of window
     if (v > most) { RA_INFO("RCCL_AMD_ONESHOT_MAX_BYTES=%ld reduced to %ld (window space)", v, most); v = most; }
@@ -87,6 +91,7 @@ void readTunables(ncclComm* c) {
   // NCCL_PROTO (src/graph/tuning.cc:476-485): "Simple" keeps small all-reduces off the low-latency path
   const char* pr = getenv("NCCL_PROTO");
   c->allowLL = !(pr && *pr && !strcasestr(pr, "LL"));
+  c->explicitLL = pr && *pr && strcasestr(pr, "LL") && !strcasestr(pr, "Simple");
   c->algoEnv = -1;
   const char* a = getenv("NCCL_ALGO");    // src/graph/tuning.cc:476-485
   if (a && *a) {

@@ -56,6 +56,7 @@ struct ncclComm {
   int blockThreads = 512;
   int algoEnv = -1;          // NCCL_ALGO: -1 unset
   bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol
+  bool explicitLL = false;   // NCCL_PROTO names LL and nothing else: small payloads take it under NCCL_ALGO=Ring|Tree too
   int llGrid = RA_LL_GRID;   // workgroups of a low-latency launch (the same on every rank of the communicator)
   size_t minChunkBytes = 32 << 10;
   size_t oneShotMaxBytes = 0;  // all-reduces up to this size (and above the low-latency limit) run as one exchange
@@ -127,7 +128,7 @@ struct RaCollArgs {
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
 ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, bool allowLL, size_t oneShotMaxBytes, RaPlan* plan);
+                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, RaPlan* plan);
 ncclResult_t raEnqueue(const RaCollArgs& a);
 ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();

@@ -244,7 +244,7 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
 // (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
 // and NCCL_ALGO selects the ring or chain schedules.
 ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, bool allowLL, size_t oneShotMaxBytes, RaPlan* p) {
+                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, RaPlan* p) {
   const size_t es = raTypeSize(dtype);
   if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
   int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
@@ -319,7 +319,16 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   size_t llMax = n <= 4 ? (size_t)RA_LL_MAX_BYTES : (size_t)RA_LL_DEFAULT_BYTES;
   if (llEnv > 0) llMax = llEnv > (long)RA_LL_MAX_BYTES ? (size_t)RA_LL_MAX_BYTES : (size_t)llEnv;
   if (rooted && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
-  if (allowLL && algo == RA_ALGO_DIRECT && n > 1 && count * es <= llMax) {
+  // Where the one-exchange protocol takes over, it does so from 512 KiB: it moves plain packs (half the bytes of the
+  // line protocol) and measured 14.7 us against 18 us at 1 MiB (two ranks sharing a GPU), 13 us against 10 us at 512 KiB.
+  if (coll == RA_COLL_ALLREDUCE && llEnv <= 0 && oneShotMaxBytes >= (size_t)RA_LL_MAX_BYTES && llMax > (size_t)RA_LL_DEFAULT_BYTES)
+    llMax = (size_t)RA_LL_DEFAULT_BYTES;
+  // allowLL 2 (NCCL_PROTO=LL asked for by name): small payloads take the line protocol under NCCL_ALGO=Ring|Tree too.
+  // The reference runs its LL primitives along the ring or tree there (src/device/all_reduce.h:358-551, prims_ll.h);
+  // here the line protocol exists as the one-hop exchange on the all-pairs links only, so that is what such a launch
+  // becomes (same result on every rank, rank-order fold).
+  if (allowLL && (algo == RA_ALGO_DIRECT || allowLL == 2) && n > 1 && count * es <= llMax) {
+    p->algo = RA_ALGO_DIRECT;
     p->proto = 1;
     p->pairRoles = 0;
     p->nChannels = RA_LL_GRID;
@@ -346,7 +355,7 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
   RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
-                     c->blockThreads, c->allowLL && !c->net, c->lay.osBytes ? c->oneShotMaxBytes : 0, p));
+                     c->blockThreads, c->net || !c->allowLL ? 0 : c->explicitLL ? 2 : 1, c->lay.osBytes ? c->oneShotMaxBytes : 0, p));
   if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }
   if (p->proto == 2) { p->nChannels = c->osGrid; p->grid = c->osGrid; }
   return ncclSuccess;

@@ -351,6 +351,16 @@ def test_low_latency_protocol(bed):
             outs = bed.run(COLL_ALLGATHER, dt, orc.SUM, count, ins, count * n * _es(dt), in_place=in_place, iters=1 if in_place else 3)
             for o in outs:
                 assert ex.check(dt, o, orc.all_gather_expected(ins), exact=True) is None, (dt, count)
+    # NCCL_PROTO=LL asked for by name together with NCCL_ALGO=Ring|Tree (the reference's LL ring / LL tree,
+    # src/device/all_reduce.h:358-551): small payloads take the one-hop line protocol, larger ones keep the named schedule
+    for algo in ("Tree", "Ring"):
+        bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": "LL"})
+        plan = bed.plan(COLL_ALLREDUCE, 1250, orc.I32)
+        assert plan["proto"] == 1 and plan["algo"] == ex.ALGO_DIRECT, plan
+        assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["algo"] == ALGOS[algo]
+        _check_allreduce(bed, orc.I32, orc.SUM, 1250)
+        _check_allreduce(bed, orc.BF16, orc.SUM, 40001)
+        _check_allreduce(bed, orc.F32, orc.SUM, 1 << 19)
     bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
 
 
