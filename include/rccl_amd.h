@@ -156,7 +156,8 @@ ncclResult_t ncclBcast(void* buff, size_t count, ncclDataType_t datatype, int ro
 
 /* ---- communicator split --------------------------------------------------------------------- */
 /* Ranks that pass the same colour form a new communicator, ordered by (key, rank in `comm`); NCCL_SPLIT_NOCOLOR
- * leaves *newcomm NULL.  Collective over `comm`: every rank must call it. */
+ * leaves *newcomm NULL.  Collective over `comm`: every rank must call it (one thread that owns several ranks: inside
+ * ncclGroupStart/End).  config NULL: the new communicator is blocking or not as its parent is. */
 ncclResult_t ncclCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcomm,
                            ncclConfig_t* config);                                        /* nccl.h.in:247 */
 
