@@ -39,38 +39,31 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 template <int WM> struct f8_t { uint8_t v; };
 typedef f8_t<3> f8e4m3_t;
 typedef f8_t<2> f8e5m2_t;
+// Both directions are branch-free (a dozen and about twenty integer / float instructions): checked against the
+// reference's conversions for all 256 codes and all 2^32 floats.
 template <int WM> __device__ __forceinline__ float f8ToF(f8_t<WM> a) {
   constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1);
-  const uint32_t x = a.v;
-  if (x == 0) return 0.0f;
-  if (x == 0x80) return __uint_as_float(0x7f800001u);
-  const uint32_t sign = (x >> 7) << 31, e = (x & 0x7f) >> WM, m = x & ((1u << WM) - 1u);
-  if (e == 0) return __uint_as_float(__float_as_uint((float)m * __uint_as_float((uint32_t)(127 + 1 - BIAS - WM) << 23)) | sign);
-  return __uint_as_float(sign | ((e + 127 - BIAS) << 23) | (m << (23 - WM)));
+  const uint32_t x = a.v, mag = x & 0x7fu;
+  const float fn = __uint_as_float((mag << (23 - WM)) + ((uint32_t)(127 - BIAS) << 23));            // normal codes
+  const float fs = (float)mag * __uint_as_float((uint32_t)(127 + 1 - BIAS - WM) << 23);             // exponent field 0
+  const float f = __uint_as_float(__float_as_uint((mag >> WM) ? fn : fs) | ((x & 0x80u) << 24));
+  return x == 0x80u ? __uint_as_float(0x7f800001u) : f;
 }
-template <int WM> __device__ __forceinline__ f8_t<WM> fToF8(float f) {
-  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1), MAXEXP = (1 << WE) - 1;
-  f8_t<WM> r;
-  const uint32_t u = __float_as_uint(f);
-  if ((u & 0x7f800000u) == 0x7f800000u) { r.v = 0x80; return r; }
-  const uint32_t sign = (u >> 31) << 7;
-  const float a = __uint_as_float(u & 0x7fffffffu);
-  int E = (int)((u >> 23) & 0xffu) - 127;
-  if (E == -127) { r.v = 0; return r; }                  // zero or a float subnormal: far below half a quantum
-  int expField, mant;
-  if (E < 1 - BIAS) {                                    // below the smallest normal: fixed quantum 2^(1-BIAS-WM)
-    const int q = (int)rintf(a * __uint_as_float((uint32_t)(127 + BIAS - 1 + WM) << 23));
-    if (q == 0) { r.v = 0; return r; }
-    if (q >= (1 << WM)) { expField = 1; mant = q - (1 << WM); } else { expField = 0; mant = q; }
-  } else {
-    int q = (int)rintf(a * __uint_as_float((uint32_t)(127 - (E - WM)) << 23));   // in [2^WM, 2^(WM+1)]
-    if (q == (1 << (WM + 1))) { E++; q = 1 << WM; }
-    expField = E + BIAS;
-    mant = q - (1 << WM);
-  }
-  if (expField > MAXEXP) { r.v = (uint8_t)(sign | 0x7f); return r; }
-  r.v = (uint8_t)(sign | ((uint32_t)expField << WM) | (uint32_t)mant);
-  return r;
+template <int WM> __device__ __forceinline__ f8_t<WM> fToF8(float v) {
+  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1);
+  const uint32_t u = __float_as_uint(v), sign = (u >> 24) & 0x80u, a = u & 0x7fffffffu;
+  constexpr uint32_t minNormal = (uint32_t)(127 + 1 - BIAS) << 23;
+  // normal range: round to nearest even on the 23-WM dropped bits (a carry moves into the exponent), then rebias
+  const uint32_t r = a + ((a >> (23 - WM)) & 1u) + ((1u << (22 - WM)) - 1u);
+  const uint32_t cn = (r >> (23 - WM)) - ((uint32_t)(127 - BIAS) << WM);
+  // below the smallest normal: adding 2^(1-BIAS-WM+23) makes the adder round to the fixed quantum 2^(1-BIAS-WM)
+  constexpr uint32_t magic = (uint32_t)(127 + 1 - BIAS - WM + 23) << 23;
+  const uint32_t cs = __float_as_uint(__uint_as_float(a) + __uint_as_float(magic)) - magic;
+  uint32_t c = a >= minNormal ? cn : cs;
+  c = c > 0x7fu ? 0x7fu : c;                             // clipped to the largest finite value
+  f8_t<WM> out;
+  out.v = (uint8_t)(a >= 0x7f800000u ? 0x80u : (c ? (sign | c) : 0u));   // infinity / NaN -> 0x80; no negative zero
+  return out;
 }
 
 template <typename T> struct IsInt { static constexpr bool value = true; };
@@ -180,11 +173,12 @@ template <typename T, int OP> struct PackOps {
     return x.v;
   }
 };
-// The 8-bit floats convert in software (about 40 instructions each way), so their pack ops stay out
-// of line, four elements per call: the copy loops around them keep their shape and the code stays small.
+// The 8-bit floats convert in software (two decodes, the operation and an encode: about 45 instructions per element),
+// so their pack ops stay out of line, four elements per call: the copy loops around them keep their shape and the
+// code stays small.
 template <int WM, int R> __device__ __noinline__ uint32_t f8Red4(uint32_t a, uint32_t b) {
   uint32_t r = 0;
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     f8_t<WM> x, y; x.v = (uint8_t)(a >> (8 * i)); y.v = (uint8_t)(b >> (8 * i));
     r |= (uint32_t)Elem<f8_t<WM>, R>::red(x, y).v << (8 * i);
@@ -193,7 +187,7 @@ template <int WM, int R> __device__ __noinline__ uint32_t f8Red4(uint32_t a, uin
 }
 template <int WM> __device__ __noinline__ uint32_t f8Pre4(uint32_t a, uint32_t arg) {
   uint32_t r = 0;
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < 4; i++) {
     f8_t<WM> x; x.v = (uint8_t)(a >> (8 * i));
     r |= (uint32_t)Scale<f8_t<WM>>::pre(x, arg).v << (8 * i);
