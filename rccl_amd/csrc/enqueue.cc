@@ -202,7 +202,11 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e;
-  if (p.proto == 1 && (a.coll == RA_COLL_ALLGATHER || a.coll == RA_COLL_BROADCAST)) {
+  if (p.proto == 2 && a.coll == RA_COLL_ALLGATHER) {
+    w.count = a.count * es;                                // bytes: the copy is the same for every element type
+    w.elemSize = 1;
+    e = raLaunchColl(c->devComm, w, ncclInt8, RA_OP_SUM, p.grid, p.block, a.stream);
+  } else if (p.proto == 1 && (a.coll == RA_COLL_ALLGATHER || a.coll == RA_COLL_BROADCAST)) {
     w.count = a.count * es;                                // bytes: the copy is the same for every element type
     e = raLaunchLL(c->devComm, w, ncclInt8, RA_OP_SUM, a.stream);
   } else if (p.proto == 1) {
@@ -321,7 +325,7 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   if (rooted && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
   // Where the one-exchange protocol takes over, it does so from 512 KiB: it moves plain packs (half the bytes of the
   // line protocol) and measured 14.7 us against 18 us at 1 MiB (two ranks sharing a GPU), 13 us against 10 us at 512 KiB.
-  if (coll == RA_COLL_ALLREDUCE && llEnv <= 0 && oneShotMaxBytes >= (size_t)RA_LL_MAX_BYTES && llMax > (size_t)RA_LL_DEFAULT_BYTES)
+  if (!rooted && llEnv <= 0 && oneShotMaxBytes >= (size_t)RA_LL_MAX_BYTES && llMax > (size_t)RA_LL_DEFAULT_BYTES)
     llMax = (size_t)RA_LL_DEFAULT_BYTES;
   // allowLL 2 (NCCL_PROTO=LL asked for by name): small payloads take the line protocol under NCCL_ALGO=Ring|Tree too.
   // The reference runs its LL primitives along the ring or tree there (src/device/all_reduce.h:358-551, prims_ll.h);
@@ -340,7 +344,13 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // into every peer's window and folds the n contributions itself, in rank order.  The three flag-synchronised phases
   // of the FIFO schedule become one push and one fold, for (n-1) x S link bytes per rank instead of 2(n-1)/n x S:
   // the same bytes with two ranks, twice as many with four, so the limit shrinks as the group grows (comm.cc).
-  if (coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && n > 1 && n <= RA_MAX_SRCS && count * es <= oneShotMaxBytes) {
+  // Reduce-scatter and all-gather move the same link bytes either way, so they take the exchange whenever a rank's
+  // block fits the window region (which is sized by the all-reduce limit).
+  // (All-gathers of RA_AG_ANNOUNCE_BYTES and more stay on the FIFOs: that is where registered receive buffers are
+  // written directly, and every rank has to choose the protocol from the size alone.)
+  const bool exchange = coll == RA_COLL_ALLREDUCE || coll == RA_COLL_REDUCESCATTER ||
+                        (coll == RA_COLL_ALLGATHER && count * es < RA_AG_ANNOUNCE_BYTES);
+  if (exchange && algo == RA_ALGO_DIRECT && n > 1 && n <= RA_MAX_SRCS && count * es <= oneShotMaxBytes) {
     p->proto = 2;
     p->oneShot = 1;
     p->pairRoles = 0;

@@ -22,7 +22,7 @@ RA_DECL(0) RA_DECL(1) RA_DECL(2) RA_DECL(3) RA_DECL(4) RA_DECL(5) RA_DECL(6) RA_
 #undef RA_DECL
 
 hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int op, int grid, int block, hipStream_t s) {
-  if (w.coll == RA_COLL_ALLGATHER || w.coll == RA_COLL_BROADCAST) {
+  if ((w.coll == RA_COLL_ALLGATHER && !w.oneShot) || w.coll == RA_COLL_BROADCAST) {
     hipLaunchKernelGGL(raGatherKernel, dim3(grid), dim3(block), 0, s, comm, w);
     return hipGetLastError();
   }

@@ -1673,6 +1673,10 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
     e0 = p0 * EPP;
     ne = ((size_t)b == last ? w.count : p1 * EPP) - e0;
   }
+  // Reduce-scatter (rank p is sent block p of sendbuff only; count is per rank) and all-gather (no fold: every sender's
+  // slice is copied to its block of recvbuff; launched with T = int8 and a byte count) use the same exchange, with the
+  // same link bytes as their FIFO schedules, so they take it at every size the window region has room for.
+  const bool scatter = w.coll == RA_COLL_REDUCESCATTER, gather = w.coll == RA_COLL_ALLGATHER;
   const T* in = (const T*)w.send + e0;
   T* out = (T*)w.recv + e0;
   const size_t boff = e0 * sizeof(T);
@@ -1684,10 +1688,20 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
     for (int i = 0; i < n - 1; i++) {
       const int p = (r + 1 + (i + b) % (n - 1)) % n;            // workgroups start on different links
       rc.dst[i] = comm->win[p] + raOsDataOffset(comm->lay, buf, r) + boff;
+      if (scatter) rc.src[i] = (const char*)(in + (size_t)p * w.count);
     }
     __syncthreads();                               // `aborted` is initialised
-    if (OP == RA_OP_PREMULSUM) rcWG<T, OP>(rc, ne, tid, nthr);
-    else copyWG(rc, ne * sizeof(T), tid, nthr);
+    if (scatter && OP != RA_OP_PREMULSUM) {
+      rc.ns = n - 1;                               // n-1 independent copies, block p to rank p
+      pairCopyWG<true>(rc, ne * sizeof(T), tid, nthr);
+    } else if (scatter) {
+      RcArgs one; one.ns = 1; one.nd = 1; one.preIdx = 0; one.post = false; one.nLocal = 0; one.opArg = w.opArg;
+      for (int i = 0; i < n - 1; i++) { one.src[0] = rc.src[i]; one.dst[0] = rc.dst[i]; rcWG<T, OP>(one, ne, tid, nthr); }
+    } else if (OP == RA_OP_PREMULSUM) {
+      rcWG<T, OP>(rc, ne, tid, nthr);
+    } else {
+      copyWG(rc, ne * sizeof(T), tid, nthr);
+    }
     drainVmem();                                   // every wave: its stores are at their destination
     __syncthreads();
     if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), epoch);
@@ -1696,14 +1710,29 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
       raSpin(comm, &aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), epoch);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
-    rc.ns = n; rc.nd = 1; rc.preIdx = r; rc.post = true; rc.nLocal = 1;
-    for (int j = 0; j < n; j++)
-      rc.src[j] = j == r ? (const char*)in : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
-    rc.dst[0] = (char*)out;
+    if (gather) {
+      // every sender's slice to its block of recvbuff (my own from sendbuff, unless it is already there)
+      int np = 0;
+      for (int j = 0; j < n; j++) {
+        char* dst = (char*)out + (size_t)j * w.count * sizeof(T);
+        const char* src = j == r ? (const char*)in : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
+        if (j == r && src == dst) continue;
+        rc.src[np] = src; rc.dst[np] = dst; np++;
+      }
+      rc.ns = np; rc.nd = np; rc.preIdx = -1; rc.post = false; rc.nLocal = np;
+    } else {
+      rc.ns = n; rc.nd = 1; rc.preIdx = r; rc.post = true; rc.nLocal = 1;
+      for (int j = 0; j < n; j++)
+        rc.src[j] = j == r ? (const char*)(scatter ? in + (size_t)r * w.count : in) : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
+      rc.dst[0] = (char*)out;
+    }
     if (tid < 64) drainVmem();
     __syncthreads();
-    // 3. the fold, in rank order
-    if (!aborted) rcWG<T, OP>(rc, ne, tid, nthr);
+    // 3. the fold, in rank order (all-gather: the copies)
+    if (!aborted) {
+      if (gather) pairCopyWG<false>(rc, ne * sizeof(T), tid, nthr);
+      else rcWG<T, OP>(rc, ne, tid, nthr);
+    }
   }
   __syncthreads();
   if (tid == 0) comm->osEpoch[b] = epoch;

@@ -145,16 +145,23 @@ def test_premul_sum_scalar_in_device_memory(bed):
         assert np.array_equal(outs[r].view(np.float16), full[r * count:(r + 1) * count]), r
 
 
-@pytest.mark.parametrize("algo", ["Direct", "Ring"])
+# "Direct": the default mix (line protocol, one exchange, FIFO schedule by size); "DirectFifo": the FIFO schedule at every size
+# above the line protocol's
+RS_AG_ENV = {"Direct": {"NCCL_ALGO": "Direct"}, "Ring": {"NCCL_ALGO": "Ring"},
+             "DirectFifo": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0"}}
+
+
+@pytest.mark.parametrize("algo", list(RS_AG_ENV))
 def test_reduce_scatter_cases(bed, algo):
-    bed.init_comms({"NCCL_ALGO": algo})
+    bed.init_comms(RS_AG_ENV[algo])
     n = bed.nranks
     # ReduceScatterTests.cpp: fp32 max {393216,384}; fp64/bf16 max; int32 prod in place 542357 (trimmed);
     # uint8/fp16 min in place 246; int64/uint8 avg 1024; uint32/uint64 avg (trimmed)
     cases = [(orc.F32, orc.MAX, 393216, False), (orc.F32, orc.MAX, 384, False), (orc.F64, orc.MAX, 104857, False),
              (orc.BF16, orc.MAX, 104857, False), (orc.F8E4M3, orc.MAX, 104857, False), (orc.I32, orc.PROD, 54235, True), (orc.U8, orc.MIN, 246, True),
              (orc.F16, orc.MIN, 246, True), (orc.I64, orc.AVG, 1024, False), (orc.U8, orc.AVG, 1024, False),
-             (orc.U32, orc.AVG, 648541, False), (orc.U64, orc.AVG, 64853, False), (orc.F32, orc.SUM, 1048576 + 7, False)]
+             (orc.U32, orc.AVG, 648541, False), (orc.U64, orc.AVG, 64853, False), (orc.F32, orc.SUM, 1048576 + 7, False),
+             (orc.BF16, orc.AVG, 200003, False), (orc.F32, orc.AVG, 150001, True), (orc.F32, orc.SUM, 524288 + 5, True)]
     for dt, op, count, in_place in cases:
         ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
         outs = bed.run(COLL_REDUCESCATTER, dt, op, count, ins, count * _es(dt), in_place=in_place)
@@ -166,9 +173,9 @@ def test_reduce_scatter_cases(bed, algo):
             assert ex.check(dt, outs[r], host, exact=False) is None
 
 
-@pytest.mark.parametrize("algo", ["Direct", "Ring"])
+@pytest.mark.parametrize("algo", list(RS_AG_ENV))
 def test_all_gather_cases(bed, algo):
-    bed.init_comms({"NCCL_ALGO": algo})
+    bed.init_comms(RS_AG_ENV[algo])
     n = bed.nranks
     # AllGatherTests.cpp: fp16/fp32 {1048576,500}; bf16/fp64 586; int32 in place {104857,264}; int8/int64 in place 958;
     # uint8 {1039203,2500}; uint32/uint64 896
@@ -336,9 +343,10 @@ def test_low_latency_protocol(bed):
             _check_allreduce(bed, dt, op, count)
         _check_allreduce(bed, orc.I32, orc.PROD, 384, in_place=True)
         # reduce-scatter and all-gather take the same protocol up to 256 KiB per rank (unaligned blocks included)
-        assert bed.plan(COLL_REDUCESCATTER, 1000, orc.F32)["proto"] == want_proto
-        assert bed.plan(COLL_ALLGATHER, 1000, orc.F32)["proto"] == want_proto
-        assert bed.plan(COLL_ALLGATHER, 262145, orc.F32)["proto"] == 0
+        assert bed.plan(COLL_REDUCESCATTER, 1000, orc.F32)["proto"] == (want_proto or 2)
+        assert bed.plan(COLL_ALLGATHER, 1000, orc.F32)["proto"] == (want_proto or 2)
+        assert bed.plan(COLL_ALLGATHER, 262145, orc.F32)["proto"] in (0, 2)      # 1 MiB + 4 B per rank: not the line protocol
+        assert bed.plan(COLL_ALLGATHER, 1 << 21, orc.F32)["proto"] == 0          # 8 MiB per rank: the FIFO schedule
         for dt, op, count, in_place in ((orc.F32, orc.SUM, 1000, False), (orc.I32, orc.PROD, 5423, True), (orc.U8, orc.MIN, 246, True),
                                         (orc.BF16, orc.AVG, 10481, False), (orc.F64, orc.MAX, 32768, False), (orc.I64, orc.AVG, 1023, False)):
             ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
