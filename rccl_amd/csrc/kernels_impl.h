@@ -854,6 +854,8 @@ struct Rounds {
     roundElems = (size_t)n * chunk;
     nRounds = (count + roundElems - 1) / roundElems;
   }
+  // elements of the largest piece of round g
+  __device__ __forceinline__ size_t pieceMax(size_t g) const { return (g + 1 == nRounds) ? lastChunk : chunk; }
   __device__ __forceinline__ void piece(size_t g, int j, size_t& off, size_t& nelem) const {
     const size_t base = g * roundElems;
     const size_t ck = (g + 1 == nRounds) ? lastChunk : chunk;
@@ -894,6 +896,7 @@ __device__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int 
     const size_t g = cx.ch + k * (size_t)w.nChannels;
     if (g >= R.nRounds) continue;
     const bool first = k == 0;
+    cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
     if (role == 0) {
       cx.auxSend = words && first;
       cx.step(0, 0, peers, 0, [&]() {
@@ -993,6 +996,7 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
         if (OP != RA_OP_PREMULSUM) {
@@ -1064,6 +1068,7 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
     const bool first = g == (size_t)cx.ch;
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    cx.stepBytes = (uint32_t)nb;
     if (role == 0) {
       cx.auxSend = announce && first;
       cx.step(0, 0, peers, 1, [&]() {
@@ -1118,6 +1123,7 @@ __device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    cx.stepBytes = (uint32_t)nb;
     if (role == 0) {
       cx.step(0, 0, peers, 1, [&]() {
         RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
@@ -1151,6 +1157,7 @@ __device__ void directReduce(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       cx.step(0, 0, 1u << root, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
@@ -1194,6 +1201,7 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
   T* out = (T*)w.recv;
   for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
     size_t off, ne;
+    cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
     // step 0: seed the piece behind me
     R.piece(g, (rp.ix + n - 1) % n, off, ne);
     cx.step(0, 0, nm, 0, [&]() {
@@ -1252,6 +1260,7 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     int blk = rp.order[(rp.ix + n - 1) % n];
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
@@ -1287,6 +1296,7 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
+    cx.stepBytes = (uint32_t)nb;
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
       a.src[0] = w.send + off;
@@ -1334,6 +1344,7 @@ __device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
   for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+    cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       if (leaf) {
         cx.step(0, 0, 1u << parent, 0, [&]() {
