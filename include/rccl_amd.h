@@ -284,6 +284,12 @@ ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataTy
                                   int maxChannels, size_t slotBytes, size_t minChunkBytes, int* algoOut,
                                   int* nChannels, size_t* chunkElems, size_t* lastChunkElems, int* grid);
 
+/* Which protocol and schedule a collective of `count` elements takes for explicit settings (host logic only):
+ * allowLL 0 = NCCL_PROTO=Simple, 1 = default, 2 = NCCL_PROTO=LL named alone; oneShotMaxBytes = RCCL_AMD_ONESHOT_MAX_BYTES
+ * as a communicator would hold it.  proto: 0 = FIFO schedule, 1 = one-hop line protocol, 2 = one exchange. */
+ncclResult_t rcclAmdPlanProtoForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo, int allowLL,
+                                       size_t oneShotMaxBytes, int* algoOut, int* proto);
+
 /* Counters of the all-reduce gather phase on this rank since the communicator was created: pieces written
  * straight into a peer's registered receive buffer, and pieces sent through the FIFO.  Synchronous. */
 ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces);

@@ -324,6 +324,16 @@ RA_API ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncc
   return ncclSuccess;
 }
 
+RA_API ncclResult_t rcclAmdPlanProtoForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo, int allowLL,
+                                              size_t oneShotMaxBytes, int* algoOut, int* proto) {
+  if (coll < 0 || coll >= RA_NUM_COLLS || allowLL < 0 || allowLL > 2) return ncclInvalidArgument;
+  RaPlan p;
+  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, 16, 512 << 10, 32 << 10, 1024, allowLL, oneShotMaxBytes, &p));
+  if (algoOut) *algoOut = p.algo;
+  if (proto) *proto = p.proto;
+  return ncclSuccess;
+}
+
 RA_API ncclResult_t rcclAmdBootstrapAllGather(const ncclUniqueId* id, int rank, int nranks, const void* mine, void* all,
                                               size_t bytes) {
   if (!id || !mine || !all || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;

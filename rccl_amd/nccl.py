@@ -35,7 +35,7 @@ EXPORTS = [
     "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
     "ncclCommSplit", "ncclGather", "ncclScatter", "ncclAllToAll", "ncclAllToAllv", "mscclLoadAlgo", "mscclRunAlgo",
     "mscclUnloadAlgo", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
-    "rcclAmdPlanForConfig", "rcclAmdBootstrapAllGather", "rcclAmdAllReduceNoAlloc",
+    "rcclAmdPlanForConfig", "rcclAmdPlanProtoForConfig", "rcclAmdBootstrapAllGather", "rcclAmdAllReduceNoAlloc",
 ]
 EXPORTS += ["p" + name for name in EXPORTS if name.startswith(("nccl", "msccl"))]      # profiling aliases
 
@@ -111,6 +111,7 @@ def lib():
                                       ctypes.POINTER(sz)]
         L.rcclAmdPlanForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ctypes.POINTER(ci),
                                            ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
+        L.rcclAmdPlanProtoForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.rcclAmdBootstrapAllGather.argtypes = [ctypes.POINTER(ncclUniqueId), ci, ci, vp, vp, sz]
         _lib = L
     return _lib
@@ -371,6 +372,14 @@ def plan_for_config(nranks, coll, count, datatype, algo=-1, max_channels=16, slo
                                       ctypes.byref(a), ctypes.byref(c), ctypes.byref(ch), ctypes.byref(last),
                                       ctypes.byref(g)), "rcclAmdPlanForConfig")
     return {"algo": a.value, "nChannels": c.value, "chunkElems": ch.value, "lastChunkElems": last.value, "grid": g.value}
+
+
+def plan_proto_for_config(nranks, coll, count, datatype, algo=-1, allow_ll=1, one_shot_max_bytes=0):
+    """rcclAmdPlanProtoForConfig: (algo, proto) a collective takes for explicit settings (no GPU needed)."""
+    a, p = ctypes.c_int(), ctypes.c_int()
+    _check(lib().rcclAmdPlanProtoForConfig(nranks, coll, count, datatype, algo, allow_ll, one_shot_max_bytes,
+                                           ctypes.byref(a), ctypes.byref(p)), "rcclAmdPlanProtoForConfig")
+    return a.value, p.value
 
 
 def bootstrap_all_gather(unique_id, rank, nranks, mine):

@@ -71,6 +71,37 @@ def test_plan_algorithm_overrides():
     assert ra.plan_for_config(16, 0, 1 << 20, ra.ncclFloat32)["algo"] == 1
 
 
+def test_protocol_choice_by_size():
+    """Which protocol a collective takes (reference: the size switch of src/graph/tuning.cc:632-671): the one-hop line
+    protocol up to 512 KiB, one exchange up to the limit a communicator of that size holds, the FIFO schedule above;
+    NCCL_PROTO=Simple (allow_ll 0) removes the line protocol, NCCL_PROTO=LL named alone (2) extends it to ring / tree."""
+    f32, AR, RS, AG, BC, RD = ra.ncclFloat32, 0, 1, 2, 3, 4
+    K, M = 1 << 10, 1 << 20
+    lim = {2: 64 * M, 4: 4 * M, 8: 2 * M}
+    for n in (2, 4, 8):
+        proto = lambda coll, nbytes, **kw: ra.plan_proto_for_config(n, coll, nbytes // 4, f32, one_shot_max_bytes=lim[n], **kw)[1]
+        assert proto(AR, 4 * K) == 1 and proto(AR, 512 * K) == 1
+        assert proto(AR, 512 * K + 4) == 2 and proto(AR, lim[n]) == 2
+        assert proto(AR, lim[n] + 4) == 0 and proto(AR, 1 << 30) == 0
+        assert proto(AR, 4 * K, allow_ll=0) == 2                          # no line protocol: one exchange from the start
+        # reduce-scatter: the exchange at every size its window region holds; all-gather below 4 MiB per rank
+        assert proto(RS, 256 * K) == 1 and proto(RS, M) == 2 and proto(RS, lim[n]) == 2 and proto(RS, lim[n] + 4) == 0
+        assert proto(AG, 256 * K) == 1 and proto(AG, M) == 2 and proto(AG, 4 * M) == 0
+        # rooted collectives: line protocol or FIFO
+        assert proto(BC, 64 * K) == 1 and proto(BC, 2 * M) == 0 and proto(RD, 64 * K) == 1 and proto(RD, 2 * M) == 0
+        # ring / tree: FIFO, unless NCCL_PROTO=LL was asked for by name (then small payloads take the line protocol on
+        # the all-pairs links, and the plan says so)
+        for algo in (1, 2):
+            assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, one_shot_max_bytes=lim[n]) == (algo, 0)
+            assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (0, 1)
+            assert ra.plan_proto_for_config(n, AR, 1 << 24, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (algo, 0)
+    # without the exchange (limit 0, e.g. the host-staged transport) the line protocol keeps its own limits
+    assert ra.plan_proto_for_config(2, AR, M // 4, f32)[1] == 1 and ra.plan_proto_for_config(8, AR, M // 4, f32)[1] == 0
+    assert ra.plan_proto_for_config(2, AR, 2 * M // 4, f32)[1] == 0
+    # more than 8 ranks: no all-pairs fold, so neither the exchange nor (by default) the line protocol
+    assert ra.plan_proto_for_config(16, AR, 1000, f32, one_shot_max_bytes=2 * M) == (1, 0)
+
+
 def test_expected_builder_orders():
     """tests/expected.py: direct == rank-order fold; ring/tree differ from it only within tolerance."""
     n, count = 4, 70001
