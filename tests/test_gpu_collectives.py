@@ -393,6 +393,13 @@ def test_hip_graph_capture_and_replay(bed):
     outs = bed.run(COLL_REDUCESCATTER, orc.F64, orc.MAX, count, ins, count * 8, graph=True)
     for r in range(n):
         assert ex.check(orc.F64, outs[r], orc.reduce_scatter_expected(orc.F64, orc.MAX, ins, r), exact=True) is None
+    # a mid-size all-reduce (one exchange): its launch parity comes from device memory, so replays alternate the buffers too
+    count = 300001
+    assert bed.plan(COLL_ALLREDUCE, count, orc.F32)["proto"] == 2
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    outs = bed.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4, graph=True)
+    for o in outs:
+        assert ex.check(orc.F32, o, orc.device_fold(orc.F32, orc.SUM, ins), exact=True) is None
     count = 1001                      # small enough for the low-latency protocol: its line flags survive a replay too
     ins = [orc.fill_pattern(orc.I32, count * n, r) for r in range(n)]
     outs = bed.run(COLL_REDUCESCATTER, orc.I32, orc.SUM, count, ins, count * 4, graph=True)
