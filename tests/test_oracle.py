@@ -65,7 +65,7 @@ def test_golden_fp8_matches_reference_header():
         assert L.orc_f32_to_f8e5m2(float(x)) == rows[i][2], (hex(rows[i][0]), "e5m2")
 
 
-def test_survey_known_values():
+def test_sixteen_bit_known_values():
     # 1/3 + 1/7 in the 16-bit formats, computed with the HIP host headers: f16 0x379e, bf16 0x3ef4
     for dt, want in ((orc.F16, 0x379E), (orc.BF16, 0x3EF4)):
         cvt = orc.f32_to_f16_bits if dt == orc.F16 else orc.f32_to_bf16_bits

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile set: N=1 bench alone and under rocprofv3 (kernel trace), PMC passes for its HBM traffic,
+# Profile set: N=1 bench alone and under rocprofv3 (kernel trace), PMC passes for its HBM traffic,
 # 2-rank loop-back (both ranks on one GPU) under rocprofv3 and with step timers.  Results under gpurun_out/r02/.
 set -o pipefail
 R=$PWD
