@@ -285,10 +285,11 @@ ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncclDataTy
                                   int* nChannels, size_t* chunkElems, size_t* lastChunkElems, int* grid);
 
 /* Which protocol and schedule a collective of `count` elements takes for explicit settings (host logic only):
- * allowLL 0 = NCCL_PROTO=Simple, 1 = default, 2 = NCCL_PROTO=LL named alone; oneShotMaxBytes = RCCL_AMD_ONESHOT_MAX_BYTES
- * as a communicator would hold it.  proto: 0 = FIFO schedule, 1 = one-hop line protocol, 2 = one exchange. */
+ * allowLL 0 = NCCL_PROTO=Simple, 1 = default, 2 = NCCL_PROTO=LL named alone; oneShotMaxBytes / twoExchangeMaxBytes =
+ * RCCL_AMD_ONESHOT_MAX_BYTES / RCCL_AMD_TWO_EXCHANGE_MAX_BYTES as a communicator would hold them.
+ * proto: 0 = FIFO schedule, 1 = one-hop line protocol, 2 = one exchange, 3 = two exchanges. */
 ncclResult_t rcclAmdPlanProtoForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo, int allowLL,
-                                       size_t oneShotMaxBytes, int* algoOut, int* proto);
+                                       size_t oneShotMaxBytes, size_t twoExchangeMaxBytes, int* algoOut, int* proto);
 
 /* Counters of the all-reduce gather phase on this rank since the communicator was created: pieces written
  * straight into a peer's registered receive buffer, and pieces sent through the FIFO.  Synchronous. */

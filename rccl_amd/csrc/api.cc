@@ -315,7 +315,7 @@ RA_API ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncc
                                          size_t* chunkElems, size_t* lastChunkElems, int* grid) {
   if (coll < 0 || coll > RA_COLL_ALLGATHER) return ncclInvalidArgument;
   RaPlan p;
-  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, maxChannels, slotBytes, minChunkBytes, 1024, 0, 0, &p));
+  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, maxChannels, slotBytes, minChunkBytes, 1024, 0, 0, 0, &p));
   if (algoOut) *algoOut = p.algo;
   if (nChannels) *nChannels = p.nChannels;
   if (chunkElems) *chunkElems = p.chunkElems;
@@ -325,10 +325,10 @@ RA_API ncclResult_t rcclAmdPlanForConfig(int nranks, int coll, size_t count, ncc
 }
 
 RA_API ncclResult_t rcclAmdPlanProtoForConfig(int nranks, int coll, size_t count, ncclDataType_t datatype, int algo, int allowLL,
-                                              size_t oneShotMaxBytes, int* algoOut, int* proto) {
+                                              size_t oneShotMaxBytes, size_t twoExchangeMaxBytes, int* algoOut, int* proto) {
   if (coll < 0 || coll >= RA_NUM_COLLS || allowLL < 0 || allowLL > 2) return ncclInvalidArgument;
   RaPlan p;
-  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, 16, 512 << 10, 32 << 10, 1024, allowLL, oneShotMaxBytes, &p));
+  RA_CHECK(raPlanFor(nranks, coll, count, datatype, algo, 16, 512 << 10, 32 << 10, 1024, allowLL, oneShotMaxBytes, twoExchangeMaxBytes, &p));
   if (algoOut) *algoOut = p.algo;
   if (proto) *proto = p.proto;
   return ncclSuccess;

@@ -14,6 +14,7 @@
 #include <strings.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <map>
 #include <thread>
 
@@ -87,6 +88,14 @@ void readTunables(ncclComm* c) {
     const long most = (256L << 20) / c->nRanks;        // two buffers for every sender: at most 512 MiB of window
     if (v > most) { RA_INFO("RCCL_AMD_ONESHOT_MAX_BYTES=%ld reduced to %ld (window space)", v, most); v = most; }
     c->oneShotMaxBytes = v > 0 ? (size_t)v : 0;
+    // Above that, up to RCCL_AMD_TWO_EXCHANGE_MAX_BYTES, an all-reduce of more than two ranks runs as two exchanges:
+    // the link bytes of the three-phase schedule without its FIFOs and credits (gradient-bucket sizes; the default
+    // needs 2 x 2 x 64 MiB of window).  Larger payloads keep the pipelined FIFO schedule, whose phases overlap on the
+    // links; here a workgroup's push, fold and copy follow one another.  With ranks sharing one GPU two exchanges
+    // measured 2.5 times faster at 8 MiB, 1.7 times at 32 MiB and still 1.3 times at 128 MiB (8 ranks).
+    long t = envLong("RCCL_AMD_TWO_EXCHANGE_MAX_BYTES", c->nRanks > 2 ? (64L << 20) : 0);
+    if (t > (128L << 20)) t = 128L << 20;
+    c->twoExMaxBytes = (c->nRanks > 2 && t > 0) ? (size_t)t : 0;
   }
   // NCCL_PROTO (src/graph/tuning.cc:476-485): "Simple" keeps small all-reduces off the low-latency path
   const char* pr = getenv("NCCL_PROTO");
@@ -126,7 +135,11 @@ void makeLayout(ncclComm* c) {
   l.llOffset = alignUp(raDataOffset(l, l.nChannels, 0, 0), 4096);   // one past the last FIFO
   l.llBytes = (size_t)RA_LL_MAX_BYTES * 2;                          // 16-byte line per 8 bytes of payload
   l.osFlagOffset = alignUp(raLLOffset(l, 2, 0), 4096);
-  l.osBytes = staged ? 0 : alignUp(c->oneShotMaxBytes, 4096);
+  // one sender's share of a buffer: a whole payload of the one-exchange limit, or two pieces (one per exchange) of
+  // the two-exchange limit
+  size_t share = c->oneShotMaxBytes;
+  if (c->twoExMaxBytes) share = std::max(share, 2 * (c->twoExMaxBytes / (size_t)c->nRanks + 2048));
+  l.osBytes = staged ? 0 : alignUp(share, 4096);
   l.osDataOffset = l.osFlagOffset + (l.osBytes ? alignUp((size_t)2 * RA_OS_MAX_GRID * l.nRanks * RA_FLAG_STRIDE, 4096) : 0);
   l.totalBytes = raOsDataOffset(l, 2, 0);
 }

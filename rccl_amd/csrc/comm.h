@@ -60,6 +60,7 @@ struct ncclComm {
   int llGrid = RA_LL_GRID;   // workgroups of a low-latency launch (the same on every rank of the communicator)
   size_t minChunkBytes = 32 << 10;
   size_t oneShotMaxBytes = 0;  // all-reduces up to this size (and above the low-latency limit) run as one exchange
+  size_t twoExMaxBytes = 0;    // ... and up to this size as two exchanges (bandwidth-optimal, more than two ranks)
 
   // device resources
   RaWindowLayout lay{};
@@ -128,7 +129,7 @@ struct RaCollArgs {
 };
 ncclResult_t raPlan(const ncclComm* comm, int coll, size_t count, int dtype, RaPlan* plan);
 ncclResult_t raPlanFor(int nRanks, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, RaPlan* plan);
+                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, size_t twoExMaxBytes, RaPlan* plan);
 ncclResult_t raEnqueue(const RaCollArgs& a);
 ncclResult_t raGroupStart();
 ncclResult_t raGroupEnd();

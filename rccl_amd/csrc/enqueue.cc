@@ -248,7 +248,7 @@ ncclResult_t checkArgs(const RaCollArgs& a, const char* name) {
 // (it moves the same 2(n-1)/n bytes per link pair as a ring in 2 steps instead of 2(n-1)),
 // and NCCL_ALGO selects the ring or chain schedules.
 ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, int maxChannels, size_t slotBytes,
-                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, RaPlan* p) {
+                       size_t minChunkBytes, int blockThreads, int allowLL, size_t oneShotMaxBytes, size_t twoExMaxBytes, RaPlan* p) {
   const size_t es = raTypeSize(dtype);
   if (es == 0 || n < 1 || maxChannels < 1 || slotBytes < 16) return ncclInvalidArgument;
   int algo = algoEnv >= 0 ? algoEnv : RA_ALGO_DIRECT;
@@ -359,15 +359,27 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
     p->block = 1024;
     p->chunkElems = count;
     p->lastChunkElems = count;
+  } else if (coll == RA_COLL_ALLREDUCE && algo == RA_ALGO_DIRECT && n > 2 && n <= RA_MAX_SRCS && count * es <= twoExMaxBytes) {
+    // Two exchanges (proto 3): reduce-scatter exchange, fold, all-gather exchange on the same window region and flags;
+    // 2(n-1)/n x S link bytes like the three-phase schedule, two flag exchanges instead of three FIFO steps.
+    p->proto = 3;
+    p->oneShot = 2;
+    p->pairRoles = 0;
+    p->nChannels = 64;
+    p->grid = 64;
+    p->block = 1024;
+    p->chunkElems = count;
+    p->lastChunkElems = count;
   }
   return ncclSuccess;
 }
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
   RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
-                     c->blockThreads, c->net || !c->allowLL ? 0 : c->explicitLL ? 2 : 1, c->lay.osBytes ? c->oneShotMaxBytes : 0, p));
+                     c->blockThreads, c->net || !c->allowLL ? 0 : c->explicitLL ? 2 : 1, c->lay.osBytes ? c->oneShotMaxBytes : 0,
+                     c->lay.osBytes ? c->twoExMaxBytes : 0, p));
   if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }
-  if (p->proto == 2) { p->nChannels = c->osGrid; p->grid = c->osGrid; }
+  if (p->proto >= 2) { p->nChannels = c->osGrid; p->grid = c->osGrid; }
   return ncclSuccess;
 }
 

@@ -1655,6 +1655,107 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaAr
   }
 }
 
+// ------------------------------------------------------------------ all-reduce in two exchanges (bucket-size payloads)
+// The bandwidth-optimal all-pairs all-reduce (2(n-1)/n x S link bytes per rank, like the three-phase FIFO schedule) on the
+// machinery of the one-exchange kernel: no FIFOs, no credits, two flag exchanges per launch.  The payload is cut into n
+// pieces (piece j is folded by rank j, whole 1 KiB rows), and workgroup b of every rank handles the same slice of every
+// piece: (1) it pushes its input of piece p's slice into rank p's window, for every peer p, and raises the first flag;
+// (2) when the peers' first flags are up it folds its own piece's slice in rank order, writes the result to recvbuff
+// and into every peer's window, and raises the second flag; (3) when the peers' second flags are up it copies their
+// finished slices into recvbuff.  A buffer of the window region holds n slots of one piece for the first exchange and
+// n for the second.  In place: a slice of recvbuff is written only by the workgroup that has already read it.
+template <typename T, int OP>
+__device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uint64_t epoch, int* aborted) {
+  const int n = comm->nRanks, r = comm->rank, tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+  const int buf = (int)(epoch & 1u);
+  constexpr size_t ROW = 64 * (16 / sizeof(T));                      // elements of a 1 KiB row
+  const size_t pe = ((w.count + n - 1) / n + ROW - 1) / ROW * ROW;   // elements of a piece
+  const size_t se = ((pe + gridDim.x - 1) / gridDim.x + ROW - 1) / ROW * ROW;   // ... of it one workgroup handles
+  const size_t s0 = (size_t)b * se;
+  if (s0 >= pe) return;                                               // the same on every rank: no flags either
+  const size_t s1 = s0 + se < pe ? s0 + se : pe;
+  auto slice = [&](int j, size_t& off, size_t& ne) {                  // my slice of piece j, clipped to the payload
+    const size_t lo = (size_t)j * pe + s0, hi = (size_t)j * pe + s1;
+    off = lo < w.count ? lo : w.count;
+    ne = lo < w.count ? (hi < w.count ? hi : w.count) - lo : 0;
+  };
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const size_t peB = pe * sizeof(T), sB = s0 * sizeof(T);
+  const size_t area1 = raOsDataOffset(comm->lay, buf, 0), area2 = area1 + (size_t)n * peB;
+  // 1. my input of every peer's piece
+  {
+    RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+    size_t ne0 = 0; bool same = OP != RA_OP_PREMULSUM;
+    for (int i = 0; i < n - 1; i++) {
+      const int p = (r + 1 + (i + b) % (n - 1)) % n;                  // workgroups start on different links
+      size_t off, ne; slice(p, off, ne);
+      if (i == 0) ne0 = ne; else same = same && ne == ne0;
+      pa.src[i] = (const char*)(in + off); pa.dst[i] = comm->win[p] + area1 + (size_t)r * peB + sB;
+    }
+    if (same) {
+      pairCopyWG<true>(pa, ne0 * sizeof(T), tid, nthr);
+    } else {
+      for (int i = 0; i < n - 1; i++) {
+        const int p = (r + 1 + (i + b) % (n - 1)) % n;
+        size_t off, ne; slice(p, off, ne);
+        RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
+        a.src[0] = pa.src[i]; a.dst[0] = pa.dst[i];
+        rcWG<T, OP>(a, ne, tid, nthr);
+      }
+    }
+  }
+  drainVmem();
+  __syncthreads();
+  if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), 2 * epoch - 1);
+  // 2. my piece: fold in rank order, result to recvbuff and to everyone
+  if (tid < n && tid != r) {
+    raSpin(comm, aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), 2 * epoch - 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  if (tid < 64) drainVmem();
+  __syncthreads();
+  if (!*aborted) {
+    size_t off, ne; slice(r, off, ne);
+    RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
+    for (int j = 0; j < n; j++) a.src[j] = j == r ? (const char*)(in + off) : comm->win[r] + area1 + (size_t)j * peB + sB;
+    a.dst[0] = (char*)(out + off); a.nLocal = 1;
+    for (int i = 1; i < n; i++) a.dst[i] = comm->win[(r + i) % n] + area2 + (size_t)r * peB + sB;
+    rcWG<T, OP>(a, ne, tid, nthr);
+  }
+  drainVmem();
+  __syncthreads();
+  if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), 2 * epoch);
+  // 3. the peers' finished pieces
+  if (tid < n && tid != r) {
+    raSpin(comm, aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), 2 * epoch);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  }
+  if (tid < 64) drainVmem();
+  __syncthreads();
+  if (!*aborted) {
+    RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0; pa.nLocal = n - 1;
+    size_t ne0 = 0; bool same = true;
+    for (int i = 0; i < n - 1; i++) {
+      const int p = (r + n - 1 - i) % n;
+      size_t off, ne; slice(p, off, ne);
+      if (i == 0) ne0 = ne; else same = same && ne == ne0;
+      pa.src[i] = comm->win[r] + area2 + (size_t)p * peB + sB; pa.dst[i] = (char*)(out + off);
+    }
+    if (same) {
+      pairCopyWG<false>(pa, ne0 * sizeof(T), tid, nthr);
+    } else {
+      for (int i = 0; i < n - 1; i++) {
+        const int p = (r + n - 1 - i) % n;
+        size_t off, ne; slice(p, off, ne);
+        RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0; a.nLocal = 1;
+        a.src[0] = pa.src[i]; a.dst[0] = pa.dst[i];
+        copyWG(a, ne * sizeof(T), tid, nthr);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ all-reduce in one exchange (mid-size payloads)
 // Every rank pushes its whole input into every peer's window and folds the n contributions itself, in rank order, so
 // all ranks end with the same bits as the all-pairs schedule gives.  Workgroup b of every rank owns the same slice of
@@ -1671,6 +1772,14 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
   const int n = comm->nRanks, r = comm->rank, tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
   if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
   const uint64_t epoch = comm->osEpoch[b] + 1;
+  if (w.oneShot == 2) {                              // all-reduce in two exchanges
+    if (tid == 0) aborted = 0;
+    __syncthreads();
+    twoExchangeAllReduce<T, OP>(comm, w, epoch, &aborted);
+    __syncthreads();
+    if (tid == 0) comm->osEpoch[b] = epoch;
+    return;
+  }
   const int buf = (int)(epoch & 1u);
   constexpr size_t EPP = 16 / sizeof(T);
   const size_t npacks = w.count / EPP;
@@ -1715,10 +1824,12 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
     }
     drainVmem();                                   // every wave: its stores are at their destination
     __syncthreads();
-    if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), epoch);
+    // (flag values: 2 x launch - 1 after the first exchange of a launch, 2 x launch after the second, which only the
+    // two-exchange all-reduce has; a line is reused two launches later, so its value only ever grows)
+    if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), 2 * epoch - 1);
     // 2. the peers' slices
     if (tid < n && tid != r) {
-      raSpin(comm, &aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), epoch);
+      raSpin(comm, &aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), 2 * epoch - 1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     if (gather) {

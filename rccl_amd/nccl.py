@@ -111,7 +111,7 @@ def lib():
                                       ctypes.POINTER(sz)]
         L.rcclAmdPlanForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ctypes.POINTER(ci),
                                            ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
-        L.rcclAmdPlanProtoForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.rcclAmdPlanProtoForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.rcclAmdBootstrapAllGather.argtypes = [ctypes.POINTER(ncclUniqueId), ci, ci, vp, vp, sz]
         _lib = L
     return _lib
@@ -374,11 +374,11 @@ def plan_for_config(nranks, coll, count, datatype, algo=-1, max_channels=16, slo
     return {"algo": a.value, "nChannels": c.value, "chunkElems": ch.value, "lastChunkElems": last.value, "grid": g.value}
 
 
-def plan_proto_for_config(nranks, coll, count, datatype, algo=-1, allow_ll=1, one_shot_max_bytes=0):
+def plan_proto_for_config(nranks, coll, count, datatype, algo=-1, allow_ll=1, one_shot_max_bytes=0, two_exchange_max_bytes=0):
     """rcclAmdPlanProtoForConfig: (algo, proto) a collective takes for explicit settings (no GPU needed)."""
     a, p = ctypes.c_int(), ctypes.c_int()
     _check(lib().rcclAmdPlanProtoForConfig(nranks, coll, count, datatype, algo, allow_ll, one_shot_max_bytes,
-                                           ctypes.byref(a), ctypes.byref(p)), "rcclAmdPlanProtoForConfig")
+                                           two_exchange_max_bytes, ctypes.byref(a), ctypes.byref(p)), "rcclAmdPlanProtoForConfig")
     return a.value, p.value
 
 

@@ -19,10 +19,13 @@ from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_BROADCAST, COLL_REDUCE,
 
 pytestmark = pytest.mark.gpu
 
-ALGOS = {"Direct": ex.ALGO_DIRECT, "Ring": ex.ALGO_RING, "Tree": ex.ALGO_TREE, "OneExchange": ex.ALGO_DIRECT}
-# "Direct": the three-phase all-pairs schedule at every size; "OneExchange": every all-reduce above the low-latency limit as
-# one exchange (the planner's choice for mid-size payloads, here forced for all sizes); other tests run the default mix.
-ALGO_ENV = {"Direct": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0"},
+ALGOS = {"Direct": ex.ALGO_DIRECT, "Ring": ex.ALGO_RING, "Tree": ex.ALGO_TREE, "OneExchange": ex.ALGO_DIRECT,
+         "TwoExchange": ex.ALGO_DIRECT}
+# "Direct": the three-phase all-pairs schedule at every size; "OneExchange" / "TwoExchange": every all-reduce above the
+# low-latency limit as one exchange / as two (the planner's choices for mid-size payloads, here forced for all sizes; two
+# exchanges exist for more than two ranks); other tests run the default mix.
+ALGO_ENV = {"Direct": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"},
+            "TwoExchange": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": str(64 << 20)},
             "Ring": {"NCCL_ALGO": "Ring", "RCCL_AMD_ONESHOT_MAX_BYTES": None},
             "Tree": {"NCCL_ALGO": "Tree", "RCCL_AMD_ONESHOT_MAX_BYTES": None},
             "OneExchange": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": str(32 << 20)}}
@@ -65,7 +68,8 @@ def _check_allreduce(bed, dt, op, count, in_place=False, pattern=True, seed=0, h
 def test_allreduce_cases(bed, algo):
     bed.init_comms(ALGO_ENV[algo])
     assert bed.plan(COLL_ALLREDUCE, 1 << 20, orc.F32)["algo"] == ALGOS[algo]
-    assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] == (2 if algo == "OneExchange" else 0)
+    want_proto = {"OneExchange": 2, "TwoExchange": 3 if bed.nranks > 2 else 0}.get(algo, 0)
+    assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] == want_proto
     # known answer: int32 sum N=1250, in[i]=i on every rank -> nranks*i (StandaloneTests.cpp:191-246)
     x = np.arange(1250, dtype=np.int32)
     outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 1250, [x] * bed.nranks, 1250 * 4)
@@ -333,7 +337,7 @@ def test_low_latency_protocol(bed):
         bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": proto})
         # (NCCL_PROTO=Simple: no line protocol; a small all-reduce is then one exchange through the FIFOs, proto 2)
         assert bed.plan(COLL_ALLREDUCE, 1250, orc.I32)["proto"] == (want_proto or 2)
-        assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] in (0, 2)     # mid-size: a FIFO protocol (one exchange or three phases)
+        assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] in (0, 2, 3)  # mid-size: one or two exchanges, or the FIFO schedule
         assert bed.plan(COLL_ALLREDUCE, 1 << 26, orc.F32)["proto"] == 0          # large: always the three-phase FIFO protocol
         outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 1250, [x] * n, 1250 * 4, iters=7)
         for o in outs:
@@ -419,7 +423,7 @@ def test_registered_receive_buffers_are_written_directly(bed):
     """ncclCommRegister (src/register.cc:154-185): with the receive buffer registered, the other ranks write their
     finished all-reduce pieces straight into it (no broadcast-phase FIFO traffic, no gather copy); results are the
     same bits as through the FIFO.  Mixed cases: only some ranks registered, in place, after deregistration."""
-    bed.init_comms({"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": "0"})    # the three-phase schedule: it has the gather phase
+    bed.init_comms({"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"})    # the three-phase schedule: it has the gather phase
     n = bed.nranks
     count = (1 << 20) + 24          # 4 MiB fp32: the FIFO protocol, several rounds on every channel
     ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]

@@ -95,6 +95,11 @@ def test_protocol_choice_by_size():
             assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, one_shot_max_bytes=lim[n]) == (algo, 0)
             assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (0, 1)
             assert ra.plan_proto_for_config(n, AR, 1 << 24, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (algo, 0)
+    # two exchanges take over above the one-exchange limit, for more than two ranks
+    for n in (4, 8):
+        p3 = lambda nbytes: ra.plan_proto_for_config(n, AR, nbytes // 4, f32, one_shot_max_bytes=lim[n], two_exchange_max_bytes=64 * M)[1]
+        assert p3(lim[n]) == 2 and p3(lim[n] + 4) == 3 and p3(64 * M) == 3 and p3(64 * M + 4) == 0
+    assert ra.plan_proto_for_config(2, AR, 100 * M // 4, f32, one_shot_max_bytes=lim[2], two_exchange_max_bytes=128 * M)[1] == 0
     # without the exchange (limit 0, e.g. the host-staged transport) the line protocol keeps its own limits
     assert ra.plan_proto_for_config(2, AR, M // 4, f32)[1] == 1 and ra.plan_proto_for_config(8, AR, M // 4, f32)[1] == 0
     assert ra.plan_proto_for_config(2, AR, 2 * M // 4, f32)[1] == 0

@@ -48,7 +48,9 @@ def main():
         algo = ["Direct", "Ring", "Tree"][int(rng.integers(0, 3))]
         proto = [None, "Simple", "LL"][int(rng.integers(0, 3))]
         exchange = [None, None, "0"][int(rng.integers(0, 3))]          # "0": the FIFO schedules at every size above the line protocol's
-        bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": proto, "RCCL_AMD_ONESHOT_MAX_BYTES": exchange})
+        two = [None, None, "0", str(64 << 20)][int(rng.integers(0, 4))]
+        bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": proto, "RCCL_AMD_ONESHOT_MAX_BYTES": exchange,
+                        "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": two})
         for _ in range(int(rng.integers(4, 12))):
             if done >= args.cases:
                 break
@@ -64,7 +66,7 @@ def main():
             in_place = bool(rng.integers(0, 2))
             pad = (int(rng.integers(0, 5)) * e, int(rng.integers(0, 5)) * e)
             root = int(rng.integers(0, n))
-            what = (f"case {done}: algo {algo} proto {proto} exchange {exchange} coll {coll} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]} count {count} "
+            what = (f"case {done}: algo {algo} proto {proto} exchange {exchange} two {two} coll {coll} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]} count {count} "
                     f"in_place {in_place} pad {pad} root {root}")
             try:
                 if coll == COLL_ALLREDUCE:
