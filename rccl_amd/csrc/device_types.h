@@ -140,7 +140,7 @@ struct RaDevComm {
   uint32_t netMode;           // 1: windows are host-pinned staging areas pumped over TCP by a proxy thread
   const RaRegSlot* regTable;  // [RA_MAX_RANKS][RA_MAX_REGS]
   uint64_t* stats;            // [0] pieces written straight into a peer's receive buffer, [1] pieces sent through the FIFO (all-reduce gather phase)
-  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 2 = no acquire fence (breaks results), 8 = agent-scope release fence before flag posts, 8 + 4 = system-scope release, 32 = step timers
+  uint32_t tuneFlags;         // measurement switches (RCCL_AMD_TUNE_FLAGS): 2 = no acquire fence (breaks results), 8 = agent-scope release fence before flag posts, 8 + 4 = system-scope release, 32 = step timers, 64 = steps that consume data dawdle before their body (slow-consumer test)
   // ring r uses order ringRanks[r][0..nRanks-1]; channel c runs ring c % nRings
   int nRings;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];

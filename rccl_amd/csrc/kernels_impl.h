@@ -264,6 +264,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ int uniformInt(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ const char* uniformPtr(const char* p) { return (const char*)uniform64((uint64_t)p); }
 __device__ __forceinline__ char* uniformPtr(char* p) { return (char*)uniform64((uint64_t)p); }
 
@@ -787,6 +788,10 @@ struct Ctx {
     __syncthreads();
     if (timed) sh->ts[1] = wall_clock64();
     const bool ok = !sh->aborted;
+    // tuneFlags 64: every step that consumes data dawdles (about 0.1 ms) before its body, so that the senders run
+    // ahead until they are held back by the credits: the slow-consumer case, which fast reducers never produce.
+    if ((comm->tuneFlags & 64) && recvMask)
+      for (int i = 0; i < 32; i++) __builtin_amdgcn_s_sleep(127);
     if (ok) body();
     if (timed) sh->ts[2] = wall_clock64();
     drainVmem();       // every wave: its loads have returned and its stores are acknowledged
@@ -850,7 +855,7 @@ struct Rounds {
   size_t count, chunk, lastChunk, roundElems, nRounds;
   int n;
   __device__ Rounds(const RaWork& w, int nRanks) {
-    n = nRanks; count = w.count; chunk = w.chunkElems; lastChunk = w.lastChunkElems;
+    n = uniformInt(nRanks); count = uniform64(w.count); chunk = uniform64(w.chunkElems); lastChunk = uniform64(w.lastChunkElems);
     roundElems = (size_t)n * chunk;
     nRounds = (count + roundElems - 1) / roundElems;
   }
@@ -875,8 +880,9 @@ __device__ __forceinline__ uint32_t peersMask(int nRanks, int rank) { return ((1
 //             and push it into every peer's window (kind 1)
 //   gather  : copy the n-1 finished pieces that arrive (kind 1) into recvbuff
 template <typename T, int OP>
-__device__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int role) {
-  const int n = cxs[0]->nRanks, r = cxs[0]->rank;
+__device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int role) {
+  const int n = uniformInt(cxs[0]->nRanks), r = uniformInt(cxs[0]->rank);
+  role = uniformInt(role); nCtx = uniformInt(nCtx);
   const Rounds R(w, n);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
@@ -890,10 +896,11 @@ __device__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int 
     for (int c = 0; c < nCtx; c++) cxs[c]->sh->auxOut[cxs[c]->tid] = w.regWord;
   // A workgroup that serves several channels (nCtx > 1: the scatter and gather roles with two ranks, see raCollKernel)
   // takes their rounds in turn, one step on each.
-  for (size_t k = 0; cxs[0]->ch + k * (size_t)w.nChannels < R.nRounds; k++)
+  const size_t stride = (size_t)uniformInt(w.nChannels);
+  for (size_t k = 0; (size_t)uniformInt(cxs[0]->ch) + k * stride < R.nRounds; k++)
    for (int c = 0; c < nCtx; c++) {
     Ctx& cx = *cxs[c];
-    const size_t g = cx.ch + k * (size_t)w.nChannels;
+    const size_t g = (size_t)uniformInt(cx.ch) + k * stride;
     if (g >= R.nRounds) continue;
     const bool first = k == 0;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
@@ -987,13 +994,14 @@ __device__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int 
 // Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers
 // elements [g*chunk, (g+1)*chunk) of every block.  Roles: scatter, reduce.
 template <typename T, int OP>
-__device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks, r = cx.rank;
+__device__ __noinline__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
+  const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
+  role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
@@ -1030,11 +1038,12 @@ __device__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
 // All-gather (bytes): roles: spread (my block into every peer's window and into my own
 // recvbuff slot unless in place), gather.
 __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks, r = cx.rank;
+  const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
+  role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const size_t nbytes = w.count * w.elemSize;          // per rank
   const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
   // Registered receive buffers (zero-copy all-gather).  A spreader may write into a peer's recvbuff only once that
   // peer's launch has begun, and it has to learn where the buffer is: for blocks of RA_AG_ANNOUNCE_BYTES and more
   // (a rule every rank evaluates alike) each gather workgroup first sends its registration word to every peer on the
@@ -1064,7 +1073,7 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
     });
     cx.auxRecv = 0;
   }
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const bool first = g == (size_t)cx.ch;
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
@@ -1114,13 +1123,14 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
 // when out of place); every other rank copies what arrives from the root.  Role of
 // src/device/broadcast.h on the all-pairs links: one hop from the root to everybody.
 __device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks, r = cx.rank, root = w.root;
+  const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank), root = uniformInt(w.root);
+  role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const size_t nbytes = w.count * w.elemSize;
   const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
   if ((role == 0) != (r == root)) return;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     cx.stepBytes = (uint32_t)nb;
@@ -1147,14 +1157,15 @@ __device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
 // Reduce to a root: every other rank pushes its input into the root's window; the root folds the n
 // contributions in rank order (role of src/device/reduce.h, one hop).
 template <typename T, int OP>
-__device__ void directReduce(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks, r = cx.rank, root = w.root;
+__device__ __noinline__ void directReduce(Ctx& cx, const RaWork& w, int role) {
+  const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank), root = uniformInt(w.root);
+  role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
+  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
   if ((role == 1) != (r == root)) return;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
@@ -1186,20 +1197,21 @@ struct RingPos {
     order = cx.comm->ringRanks[cx.ch % cx.comm->nRings];
     ix = 0;
     for (int i = 0; i < cx.nRanks; i++) if (order[i] == cx.rank) ix = i;
-    prev = order[(ix + cx.nRanks - 1) % cx.nRanks];
-    next = order[(ix + 1) % cx.nRanks];
+    prev = uniformInt(order[(ix + cx.nRanks - 1) % cx.nRanks]);
+    next = uniformInt(order[(ix + 1) % cx.nRanks]);
+    ix = uniformInt(ix);
   }
 };
 
 template <typename T, int OP>
-__device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
-  const int n = cx.nRanks;
+__device__ __noinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
+  const int n = uniformInt(cx.nRanks);
   const Rounds R(w, n);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  for (size_t g = cx.ch; g < R.nRounds; g += w.nChannels) {
+  for (size_t g = uniformInt(cx.ch); g < R.nRounds; g += (size_t)uniformInt(w.nChannels)) {
     size_t off, ne;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
     // step 0: seed the piece behind me
@@ -1250,14 +1262,14 @@ __device__ void ringAllReduce(Ctx& cx, const RaWork& w) {
 // Ring reduce-scatter (src/device/reduce_scatter.h:36-57): blocks travel in the order
 // order[n-1], ..., order[0] relative to each rank's rotated ring and finish at their owner.
 template <typename T, int OP>
-__device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
-  const int n = cx.nRanks;
+__device__ __noinline__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
+  const int n = uniformInt(cx.nRanks);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
@@ -1287,13 +1299,13 @@ __device__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
 
 // Ring all-gather (src/device/all_gather.h:69-145), bytes.
 __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
-  const int n = cx.nRanks;
+  const int n = uniformInt(cx.nRanks);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const size_t nbytes = w.count * w.elemSize;
   const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     cx.stepBytes = (uint32_t)nb;
@@ -1333,15 +1345,16 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
 // and down pipelines overlap: role 0 runs the up steps (the root's up step also starts the
 // way down), role 1 runs the down steps.  Round g covers elements [g*chunk, (g+1)*chunk).
 template <typename T, int OP>
-__device__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
-  const int n = cx.nRanks;
+__device__ __noinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
+  const int n = uniformInt(cx.nRanks);
+  role = uniformInt(role);
   const RingPos rp(cx);
   const bool root = rp.ix == 0, leaf = rp.ix == n - 1;
   const int parent = rp.prev, child = rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = (w.count + w.chunkElems - 1) / w.chunkElems;
-  for (size_t g = cx.ch; g < nRounds; g += w.nChannels) {
+  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
+  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * w.chunkElems;
     const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)

@@ -177,6 +177,24 @@ def test_reduce_scatter_cases(bed, algo):
             assert ex.check(dt, outs[r], host, exact=False) is None
 
 
+def test_integer_average_through_the_fifos(bed):
+    """ncclAvg of every integer type (sum, then divide by the rank count: FuncSumPostDiv, src/device/reduce_kernel.h:546-573)
+    on the FIFO schedules at sizes of several rounds per channel: the reducers divide, so they are the slow side and
+    the senders run into the credit limit.  Reduce-scatter with a ragged last round, then all-reduce."""
+    n = bed.nranks
+    bed.init_comms({"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"})
+    for dt in (orc.I8, orc.U8, orc.I32, orc.U32, orc.I64, orc.U64):
+        count = (2 << 20) // _es(dt) + 48          # above the line protocol's limit for every type
+        ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
+        outs = bed.run(COLL_REDUCESCATTER, dt, orc.AVG, count, ins, count * _es(dt))
+        plan = bed.plan(COLL_REDUCESCATTER, count, dt)
+        assert plan["proto"] == 0, plan
+        for r in range(n):
+            assert ex.check(dt, outs[r], ex.reduce_scatter(dt, orc.AVG, ins, r, plan)) is None, (orc.DT_NAMES[dt], r, plan)
+        _check_allreduce(bed, dt, orc.AVG, (4 << 20) // _es(dt) + 16)
+    bed.init_comms({"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None})
+
+
 @pytest.mark.parametrize("algo", list(RS_AG_ENV))
 def test_all_gather_cases(bed, algo):
     bed.init_comms(RS_AG_ENV[algo])
