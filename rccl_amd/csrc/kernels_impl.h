@@ -226,20 +226,26 @@ __device__ __forceinline__ void stAt(uint64_t base, uint32_t off, u32x4 v) { __b
 // vmcnt drains, so no cache write-back is needed before a flag that announces them, and nothing stays dirty in L2.
 // Used for every byte that leaves for a peer's window and, inside the collective kernels, for the local receive
 // buffer too (an L2 with no dirty lines makes the release fence in front of every flag post cheap).
-// The bulk form goes through a buffer descriptor (base in SGPRs, 32-bit uniform and per-lane offsets): unlike
-// inline asm it is a memory instruction the compiler knows, so its s_waitcnt vmcnt(N) counts stay exact and a
-// tile's stores can still be in flight while the next tile's loads are awaited.
+// The bulk form goes through a buffer descriptor (base in SGPRs, per-lane 32-bit offset): unlike inline asm it is a
+// memory instruction the compiler knows, so its s_waitcnt vmcnt(N) counts stay exact and a tile's stores can still be
+// in flight while the next tile's loads are awaited.
+// The descriptor carries the whole uniform part of the address and the scalar-offset field stays the constant 0.
+// With a REGISTER in that field hipcc (ROCm 7.2) treats a 16-byte buffer store as free of the store-data hazard and
+// lets the next VALU instruction overwrite the data registers; on gfx950 the store then ships the overwritten dwords
+// of some lanes (seen with the byte-wise adds of the 8-bit integer types, whose VALU work sits right behind the
+// stores: a few wrong dwords per launch).  With a constant there the compiler spaces the two by itself.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t bufRsrc(uint64_t base) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);   // raw buffer, no range limit below 4 GiB
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);   // raw buffer, no range check
 }
 #define RA_AUX_WT 19   // sc0 (1) | nt (2) | sc1 (16)
-__device__ __forceinline__ void stSysAt(rsrc_t r, uint32_t soff, uint32_t off, u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)off, (int)soff, RA_AUX_WT);
+__device__ __forceinline__ void stSysAt(uint64_t base, uint32_t off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, bufRsrc(base), (int)off, 0, RA_AUX_WT);
 }
-// Single packs of ragged ends: hipcc does not count this store; every step ends with an explicit s_waitcnt vmcnt(0).
+// Single packs of ragged ends: hipcc does not count this store (every step ends with an explicit s_waitcnt vmcnt(0))
+// and does not see its data registers either, hence the wait states behind it.
 __device__ __forceinline__ void stSys(u32x4* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 // ------------------------------------------------------------------ reduce-copy
@@ -303,9 +309,8 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
   const int nLocal = NS > 0 ? LOC : __builtin_amdgcn_readfirstlane(a.nLocal);
   auto storeTo = [&](uint64_t dk, bool wt, const u32x4 (&acc)[U], size_t b16) {
     if (wt) {
-      const rsrc_t r = bufRsrc(dk);
 #pragma unroll
-      for (int u = 0; u < U; u++) stSysAt(r, (uint32_t)b16, lane16 + (uint32_t)u * row, acc[u]);
+      for (int u = 0; u < U; u++) stSysAt(dk + b16, lane16 + (uint32_t)u * row, acc[u]);
     } else {
 #pragma unroll
       for (int u = 0; u < U; u++) stAt(dk + b16, lane16 + (uint32_t)u * row, acc[u]);
@@ -558,9 +563,8 @@ __device__ __forceinline__ size_t pairRows(const uint64_t* sIn, const uint64_t* 
 #pragma unroll
     for (int j = 0; j < NP; j++) {
       if (WT) {
-        const rsrc_t rd = bufRsrc(d[j]);
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) stSysAt(rd, (uint32_t)(b + (size_t)r * row), lane16, v[j][r]);
+        for (int r = 0; r < ROWS; r++) stSysAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
       } else {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) stAt(d[j] + b + (size_t)r * row, lane16, v[j][r]);
