@@ -63,6 +63,34 @@ def one(bed, coll, dt, op, nbytes):
     return [ex.check(dt, outs[root], orc.device_fold(dt, op, ins))], bed.plan(coll, count, dt)
 
 
+def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None):
+    """Walks the matrix on `bed`; returns the list of failures (strings).  Stops at the first rank that fails (a
+    timeout or a fault): nothing more is started on the GPU after that."""
+    failures, done, t0 = [], 0, time.time()
+    for name, cfg, colls in [c for c in CONFIGS if configs in c[0]] * repeat:
+        bed.init_comms(cfg)
+        for coll in colls:
+            if coll == COLL_REDUCE and bed.nranks > 8:
+                continue
+            for dt in dtypes or DTYPES:
+                for op in OPS:
+                    what = f"{name}: {NAMES[coll]} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]}"
+                    done += 1
+                    try:
+                        bad, plan = one(bed, coll, dt, op, nbytes)
+                    except Exception as exc:  # noqa: BLE001
+                        failures.append(f"STOPPED at {what}: {repr(exc)[:300]}")
+                        return failures
+                    bad = [b for b in bad if b]
+                    if bad:
+                        failures.append(f"MISMATCH {what} {plan} -> {bad[0][:300]}")
+                        if log:
+                            log(failures[-1])
+            if log:
+                log(f"{name}: {NAMES[coll]} done; {done} cases, {len(failures)} failures, {time.time() - t0:.0f} s")
+    return failures
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=8)
@@ -71,34 +99,16 @@ def main():
     ap.add_argument("--dtypes", default="", help="comma-separated ncclDataType_t values (default: all)")
     ap.add_argument("--repeat", type=int, default=1)
     args = ap.parse_args()
-    env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "5000"}
-    bed = TestBed(args.ranks, env=env)
-    fails, done, t0 = 0, 0, time.time()
-    dtypes = [int(x) for x in args.dtypes.split(",")] if args.dtypes else DTYPES
-    for name, cfg, colls in [c for c in CONFIGS if args.configs in c[0]] * args.repeat:
-        bed.init_comms(cfg)
-        for coll in colls:
-            if coll == COLL_REDUCE and args.ranks > 8:
-                continue
-            for dt in dtypes:
-                for op in OPS:
-                    what = f"{name}: {NAMES[coll]} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]}"
-                    done += 1
-                    try:
-                        bad, plan = one(bed, coll, dt, op, args.bytes)
-                    except Exception as exc:  # noqa: BLE001
-                        print("ERROR", what, "->", repr(exc)[:300], flush=True)
-                        bed.close()
-                        print(f"STOPPED after {done} cases: a rank failed (timeout or fault); nothing more is started")
-                        return 2
-                    bad = [b for b in bad if b]
-                    if bad:
-                        fails += 1
-                        print("MISMATCH", what, plan, "->", bad[0][:300], flush=True)
-            print(f"{name}: {NAMES[coll]} done; {done} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
-    bed.close()
-    print(f"DONE {done} cases, {fails} failures")
-    return 1 if fails else 0
+    bed = TestBed(args.ranks, env={"RCCL_AMD_SPIN_TIMEOUT_MS": "5000"})
+    try:
+        failures = run(bed, args.bytes, args.configs, [int(x) for x in args.dtypes.split(",")] if args.dtypes else None,
+                       args.repeat, log=lambda m: print(m, flush=True))
+    finally:
+        bed.close()
+    print(f"DONE, {len(failures)} failures")
+    for f in failures:
+        print(f)
+    return 1 if failures else 0
 
 
 if __name__ == "__main__":
