@@ -33,6 +33,9 @@ CONFIGS = [
     ("chain", {"NCCL_ALGO": "Tree", **FIFO}, (COLL_ALLREDUCE,)),
     ("default choice", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
      (COLL_ALLREDUCE, COLL_REDUCESCATTER)),
+    # small payloads: the low-latency line protocol (and whatever the planner picks for the other collectives there)
+    ("default choice, 160 KiB", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
+     (COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_REDUCE), 160 << 10),
 ]
 NAMES = {COLL_ALLREDUCE: "all-reduce", COLL_REDUCESCATTER: "reduce-scatter", COLL_REDUCE: "reduce",
          COLL_ALLGATHER: "all-gather", COLL_BROADCAST: "broadcast"}
@@ -67,7 +70,7 @@ def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None):
     """Walks the matrix on `bed`; returns the list of failures (strings).  Stops at the first rank that fails (a
     timeout or a fault): nothing more is started on the GPU after that."""
     failures, done, t0 = [], 0, time.time()
-    for name, cfg, colls in [c for c in CONFIGS if configs in c[0]] * repeat:
+    for name, cfg, colls, *size in [c for c in CONFIGS if configs in c[0]] * repeat:
         bed.init_comms(cfg)
         for coll in colls:
             if coll == COLL_REDUCE and bed.nranks > 8:
@@ -77,7 +80,7 @@ def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None):
                     what = f"{name}: {NAMES[coll]} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]}"
                     done += 1
                     try:
-                        bad, plan = one(bed, coll, dt, op, nbytes)
+                        bad, plan = one(bed, coll, dt, op, size[0] if size else nbytes)
                     except Exception as exc:  # noqa: BLE001
                         failures.append(f"STOPPED at {what}: {repr(exc)[:300]}")
                         return failures
