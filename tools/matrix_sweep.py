@@ -2,7 +2,7 @@
 """Every (element type, operator) kernel instantiation through every schedule once, at sizes of several rounds per
 channel, each result compared bit for bit with the CPU oracle.
 
-    python tools/matrix_sweep.py [--ranks 8] [--bytes 3145728] [--configs chain] [--dtypes 0,1] [--repeat 3]
+    python tools/matrix_sweep.py [--ranks 8] [--bytes 3145728] [--configs chain] [--dtypes 0,1] [--repeat 3] [--in-place] [--pad 3]
 
 The reducing kernels are compiled once per element type and operator, so a fault that belongs to one instantiation
 (a wrong result, a device-side wait that never ends) shows only when that pair meets the schedule in question; the
@@ -45,28 +45,28 @@ def es(dt):
     return np.dtype(orc.NP_OF[dt]).itemsize
 
 
-def one(bed, coll, dt, op, nbytes):
+def one(bed, coll, dt, op, nbytes, in_place=False, pad=None):
     n = bed.nranks
     e = es(dt)
     if coll == COLL_REDUCESCATTER:
         count = nbytes // (e * 2) + 48 // e                  # per rank
         ins = [orc.fill_pattern(dt, count * n, r) for r in range(n)]
-        outs = bed.run(coll, dt, op, count, ins, count * e)
+        outs = bed.run(coll, dt, op, count, ins, count * e, in_place=in_place, pad=pad)
         plan = bed.plan(coll, count, dt)
         return [ex.check(dt, outs[r], ex.reduce_scatter(dt, op, ins, r, plan)) for r in range(n)], plan
     count = nbytes // e + 48 // e
     ins = [orc.fill_pattern(dt, count, r) for r in range(n)]
     if coll == COLL_ALLREDUCE:
-        outs = bed.run(coll, dt, op, count, ins, count * e)
+        outs = bed.run(coll, dt, op, count, ins, count * e, in_place=in_place, pad=pad)
         plan = bed.plan(coll, count, dt)
         want = ex.allreduce(dt, op, ins, plan)
         return [ex.check(dt, outs[r], want) for r in range(n)], plan
     root = n - 1
-    outs = bed.run(coll, dt, op, count, ins, count * e, root=root)
+    outs = bed.run(coll, dt, op, count, ins, count * e, root=root, in_place=in_place, pad=pad)
     return [ex.check(dt, outs[root], orc.device_fold(dt, op, ins))], bed.plan(coll, count, dt)
 
 
-def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None):
+def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None, in_place=False, pad_elems=0):
     """Walks the matrix on `bed`; returns the list of failures (strings).  Stops at the first rank that fails (a
     timeout or a fault): nothing more is started on the GPU after that."""
     failures, done, t0 = [], 0, time.time()
@@ -80,7 +80,8 @@ def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None):
                     what = f"{name}: {NAMES[coll]} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]}"
                     done += 1
                     try:
-                        bad, plan = one(bed, coll, dt, op, size[0] if size else nbytes)
+                        bad, plan = one(bed, coll, dt, op, size[0] if size else nbytes, in_place,
+                                        (pad_elems * es(dt), pad_elems * es(dt)) if pad_elems else None)
                     except Exception as exc:  # noqa: BLE001
                         failures.append(f"STOPPED at {what}: {repr(exc)[:300]}")
                         return failures
@@ -101,11 +102,13 @@ def main():
     ap.add_argument("--configs", default="", help="only the configurations whose name contains this")
     ap.add_argument("--dtypes", default="", help="comma-separated ncclDataType_t values (default: all)")
     ap.add_argument("--repeat", type=int, default=1)
+    ap.add_argument("--in-place", action="store_true")
+    ap.add_argument("--pad", type=int, default=0, help="elements in front of both user buffers (unaligned pointers)")
     args = ap.parse_args()
     bed = TestBed(args.ranks, env={"RCCL_AMD_SPIN_TIMEOUT_MS": "5000"})
     try:
         failures = run(bed, args.bytes, args.configs, [int(x) for x in args.dtypes.split(",")] if args.dtypes else None,
-                       args.repeat, log=lambda m: print(m, flush=True))
+                       args.repeat, log=lambda m: print(m, flush=True), in_place=args.in_place, pad_elems=args.pad)
     finally:
         bed.close()
     print(f"DONE, {len(failures)} failures")
