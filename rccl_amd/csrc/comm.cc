@@ -115,10 +115,13 @@ void makeLayout(ncclComm* c) {
   RaWindowLayout& l = c->lay;
   l.nRanks = c->nRanks;
   l.nChannels = c->maxChannels;
-  // Two deep, 512 KiB slots between GPUs: the roles of a channel run in different workgroups, so one slot being
-  // filled while the other is drained is all the overlap there is to have, and the larger step halves the
-  // per-step costs (measured: 1 GiB all-reduce, ranks sharing one GPU, 2.81 -> 2.36 ms at 2 ranks, 12.4 -> 11.9 ms
-  // at 8).  The host-staged transport keeps 4 x 256 KiB: its proxy threads want more steps in flight.
+  // Two deep, 768 KiB slots between GPUs: the roles of a channel run in different workgroups, so one slot being
+  // filled while the other is drained is all the overlap there is to have, and a larger step spreads the per-step
+  // costs (measured: 1 GiB all-reduce, ranks sharing one GPU, 4 x 256 KiB -> 2 x 512 KiB: 2.81 -> 2.36 ms at 2 ranks,
+  // 12.4 -> 11.9 ms at 8; 512 KiB -> 768 KiB with the steps of a channel balanced: 1.73 -> 1.68 ms at 2 ranks,
+  // 5.53 -> 5.09 ms at 4, 10.85 -> 10.46 ms at 8; 1 MiB slots are slower again, 1.81 ms at 2 ranks).  Above 8 ranks
+  // 512 KiB, which keeps the window below the 2 GiB an IPC mapping is good for.  The host-staged transport keeps
+  // 4 x 256 KiB: its proxy threads want more steps in flight.
   const bool staged = raNetRequested() && c->multiProcess;
   long slots = envLong("RCCL_AMD_NSLOTS", staged ? 4 : 2);
   if (slots < 2) slots = 2;
@@ -127,7 +130,7 @@ void makeLayout(ncclComm* c) {
   long slotBytes = envLong("RCCL_AMD_SLOT_BYTES", -1);
   if (slotBytes <= 0) {
     long buff = envLong("NCCL_BUFFSIZE", -1);      // whole FIFO, as in src/init.cc:837-875
-    slotBytes = buff > 0 ? buff / slots : (staged ? (256 << 10) : (512 << 10));
+    slotBytes = buff > 0 ? buff / slots : (staged ? (256 << 10) : c->nRanks <= 8 ? (768 << 10) : (512 << 10));
   }
   if (slotBytes < 4096) slotBytes = 4096;
   l.slotBytes = (uint32_t)alignUp((size_t)slotBytes, 4096);

@@ -33,18 +33,22 @@ def test_allreduce_plan_geometry(n, dt, count):
 
 
 def test_plan_round_and_row_rules():
-    """Chunks are whole 1 KiB rows once they exceed the minimum; with more than two ranks a channel gets about
-    four rounds, eight where four would need chunks above 256 KiB; with two ranks one round of the largest piece
-    that fits a slot; small counts use only as many channels as have a full minimum chunk each."""
+    """Chunks are whole 1 KiB rows once they exceed the minimum and whole tiles of the copy loops once they hold four of
+    them; with more than two ranks a channel gets about four rounds, eight where four would need chunks above 256 KiB;
+    with two ranks one round of the largest piece that fits a slot; payloads of more than a slot per channel take
+    rounds of about equal size; small counts use only as many channels as have a full minimum chunk each."""
     f32 = ra.ncclFloat32
-    # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of ~293 KiB
+    # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of 304 KiB (19 tiles of 16 KiB)
     big = ra.plan_for_config(8, 0, 1 << 28, f32, max_channels=56)
     assert big["nChannels"] == 56 and big["grid"] == 168
-    assert big["chunkElems"] == 75008 and big["chunkElems"] * 4 % 1024 == 0
+    assert big["chunkElems"] == 77824 and big["chunkElems"] * 4 % (16 << 10) == 0
     rounds = -(-(1 << 28) // (8 * 56 * big["chunkElems"]))
     assert rounds == 8
-    # 1 GiB, 2 ranks, 32 channels: the slot bounds the chunk (512 KiB)
+    # 1 GiB, 2 ranks, 32 channels: the slot bounds the chunk (512 KiB given here; 768 KiB is the library's default)
     assert ra.plan_for_config(2, 0, 1 << 28, f32, max_channels=32)["chunkElems"] == (512 << 10) // 4
+    assert ra.plan_for_config(2, 0, 1 << 28, f32, max_channels=64, slot_bytes=768 << 10)["chunkElems"] == (768 << 10) // 4
+    # 128 MiB, 2 ranks, 64 channels, 768 KiB slots: 1 MiB per channel and rank -> two rounds of 512 KiB, not 768 + 256
+    assert ra.plan_for_config(2, 0, 1 << 25, f32, max_channels=64, slot_bytes=768 << 10)["chunkElems"] == (512 << 10) // 4
     # 16 MiB, 2 ranks: one round of 256 KiB per channel (with two ranks a step's cost is mostly fixed below a full slot)
     mid = ra.plan_for_config(2, 0, 1 << 22, f32, max_channels=32)
     assert mid["nChannels"] == 32 and mid["chunkElems"] == 65536
