@@ -278,7 +278,7 @@ __device__ __forceinline__ char* uniformPtr(char* p) { return (char*)uniform64((
 //
 // LOC: how many leading destinations are local memory written with plain streaming stores (a.nLocal: 0 or 1 here; the
 // receive buffer, when it is a destination, comes first); every other destination is a window slot or a peer's buffer
-// and is written with write-through stores (it then lies within 4 GiB of a.dst[k]: a slot, or a piece of at most one slot).
+// and is written with write-through stores (descriptor base = destination + tile offset, per-lane offset below one tile).
 //
 // NS > 0 (source and destination counts known at compile time): software-pipelined.  All NS*U loads of a tile are
 // issued together, and the loads of the NEXT tile are issued before this tile's stores, so a wave waits for a tile's
