@@ -344,8 +344,13 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // The reference runs its LL primitives along the ring or tree there (src/device/all_reduce.h:358-551, prims_ll.h);
   // here the line protocol exists as the one-hop exchange on the all-pairs links only, so that is what such a launch
   // becomes (same result on every rank, rank-order fold).
+  // NCCL_ALGO=Tree with NCCL_PROTO=LL: an all-reduce of up to RA_LL_DEFAULT_BYTES (its presence tokens sit beyond that
+  // in the line buffers) runs the line protocol along the chain (raLLChainKernel), folded in the chain's order.
+  const bool chainLL = allowLL == 2 && algo == RA_ALGO_TREE && coll == RA_COLL_ALLREDUCE && n <= RA_MAX_RANKS;
+  if (chainLL && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
   if (allowLL && (algo == RA_ALGO_DIRECT || allowLL == 2) && n > 1 && count * es <= llMax) {
-    p->algo = RA_ALGO_DIRECT;
+    p->algo = chainLL ? RA_ALGO_TREE : RA_ALGO_DIRECT;
+    if (chainLL) { p->chunkElems = count; p->lastChunkElems = count; }
     p->proto = 1;
     p->pairRoles = 0;
     p->nChannels = RA_LL_GRID;

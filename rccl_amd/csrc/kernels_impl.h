@@ -1620,6 +1620,68 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
 }
 
+// The line protocol along the chain (NCCL_ALGO=Tree with NCCL_PROTO=LL; role of the reference's LL tree all-reduce,
+// src/device/all_reduce.h:358-551 runTreeSplit over prims_ll.h): lines travel up the chain in ring order, every rank
+// folding its own input with what its child sent (local (op) received, the order of chainAllReduce), the root finishes
+// and the result travels back down.  A thread owns the same units on every rank, so a unit's path is one dependent
+// chain of 2(n-1) line hops with no barrier anywhere; the up pass of all of a thread's units runs before its down pass.
+// Lines of sender q live where the one-hop kernel keeps them, and the launch counter is shared with it, so every
+// workgroup exchanges a presence token with EVERY peer as the rooted one-hop collectives do: finishing a launch then
+// needs a line of that launch from every peer, which is what keeps the two alternating buffers safe under any mix.
+template <typename T, int OP>
+__global__ __launch_bounds__(RA_LL_THREADS) void raLLChainKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  const int n = comm->nRanks, r = comm->rank;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
+  uint32_t epoch = comm->llEpoch[blockIdx.x] + 1;
+  if (epoch == 0) epoch = 1;
+  const int buf = (int)(epoch & 1u);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const int8_t* order = comm->ringRanks[0];
+  int ix = 0;
+  for (int i = 0; i < n; i++) if (order[i] == r) ix = i;
+  const int parent = ix > 0 ? order[ix - 1] : -1, child = ix < n - 1 ? order[ix + 1] : -1;
+  const size_t nUnits = (w.count * sizeof(T) + 7) / 8;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+  const size_t tokenLine = RA_LL_TOKEN_LINE + blockIdx.x;
+  if ((int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line; line.x = 0; line.y = epoch; line.z = 0; line.w = epoch;
+    stSys((u32x4*)(comm->win[threadIdx.x] + raLLOffset(comm->lay, buf, r)) + tokenLine, line);
+  }
+  bool dead = false;
+  // up: own input, folded with the child's line, to the parent; the root finishes, keeps the result and starts the way down
+  for (size_t u = gtid; u < nUnits; u += gsize) {
+    uint64_t v = llLoadUnit<T>(in, u, w.count);
+    if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
+    if (child >= 0) {
+      u32x4 line;
+      llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, child) + u * 16, epoch, dead, line);
+      v = llRed<T, OP>(v, (uint64_t)line.x | ((uint64_t)line.z << 32));
+    }
+    if (parent < 0 && OP == RA_OP_SUMPOSTDIV) v = llScale<T, false>(v, w.opArg);
+    const int to = parent >= 0 ? parent : child;
+    if (to >= 0 && !dead) {
+      u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
+      stSys((u32x4*)(comm->win[to] + raLLOffset(comm->lay, buf, r)) + u, line);
+    }
+    if (parent < 0 && !dead) llStoreUnit<T>(out, u, w.count, v);
+  }
+  // down: the parent's line is the result; it goes to recvbuff and on to the child
+  for (size_t u = gtid; parent >= 0 && u < nUnits; u += gsize) {
+    u32x4 line;
+    llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, parent) + u * 16, epoch, dead, line);
+    if (dead) continue;
+    if (child >= 0) stSys((u32x4*)(comm->win[child] + raLLOffset(comm->lay, buf, r)) + u, line);
+    llStoreUnit<T>(out, u, w.count, (uint64_t)line.x | ((uint64_t)line.z << 32));
+  }
+  if ((int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line;
+    llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, (int)threadIdx.x) + tokenLine * 16, epoch, dead, line);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
+}
+
 // ------------------------------------------------------------------ the all-reduce that allocates nothing
 // Same protocol as raLLAllReduceKernel, all state in the kernel arguments: a.lines[p] is rank p's line array, the
 // lines of sender q for buffer b start at (b * RA_NA_MAX_RANKS + q) * RA_NA_SENDER_BYTES.  Ranks that share a GPU

@@ -381,16 +381,30 @@ def test_low_latency_protocol(bed):
             outs = bed.run(COLL_ALLGATHER, dt, orc.SUM, count, ins, count * n * _es(dt), in_place=in_place, iters=1 if in_place else 3)
             for o in outs:
                 assert ex.check(dt, o, orc.all_gather_expected(ins), exact=True) is None, (dt, count)
-    # NCCL_PROTO=LL asked for by name together with NCCL_ALGO=Ring|Tree (the reference's LL ring / LL tree,
-    # src/device/all_reduce.h:358-551): small payloads take the one-hop line protocol, larger ones keep the named schedule
+    # NCCL_PROTO=LL asked for by name together with NCCL_ALGO=Tree|Ring (the reference's LL tree / LL ring,
+    # src/device/all_reduce.h:358-551): under Tree small payloads run the line protocol ALONG THE CHAIN (folded in the
+    # chain's order, like the FIFO chain), under Ring they take the one-hop line protocol; larger ones keep the named schedule
     for algo in ("Tree", "Ring"):
         bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": "LL"})
         plan = bed.plan(COLL_ALLREDUCE, 1250, orc.I32)
-        assert plan["proto"] == 1 and plan["algo"] == ex.ALGO_DIRECT, plan
+        assert plan["proto"] == 1 and plan["algo"] == (ex.ALGO_TREE if algo == "Tree" else ex.ALGO_DIRECT), plan
         assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["algo"] == ALGOS[algo]
+        assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] == 0
         _check_allreduce(bed, orc.I32, orc.SUM, 1250)
         _check_allreduce(bed, orc.BF16, orc.SUM, 40001)
-        _check_allreduce(bed, orc.F32, orc.SUM, 1 << 19)
+        _check_allreduce(bed, orc.F32, orc.SUM, 1 << 17)                 # 512 KiB: the largest payload of the chain's lines
+        _check_allreduce(bed, orc.F32, orc.SUM, (1 << 17) + 1)           # one element more: the named schedule's FIFOs
+        _check_allreduce(bed, orc.F16, orc.AVG, 70001)
+        _check_allreduce(bed, orc.I8, orc.AVG, 30003, in_place=True)
+        _check_allreduce(bed, orc.F8E4M3, orc.MAX, 12888)
+        # launches of the chain's lines and of the one-hop lines share buffers and launch counters: alternate them
+        for count in (5000, 3, 70000):
+            _check_allreduce(bed, orc.F32, orc.SUM, count)
+            ins = [orc.fill_pattern(orc.I32, count * n, r) for r in range(n)]
+            outs = bed.run(COLL_REDUCESCATTER, orc.I32, orc.SUM, count, ins, count * 4)
+            rs_plan = bed.plan(COLL_REDUCESCATTER, count, orc.I32)
+            for r in range(n):
+                assert ex.check(orc.I32, outs[r], ex.reduce_scatter(orc.I32, orc.SUM, ins, r, rs_plan)) is None, (algo, count, r, rs_plan)
     bed.init_comms({"NCCL_ALGO": None, "NCCL_PROTO": None})
 
 

@@ -26,16 +26,19 @@ from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_BROADCAST, COLL_REDUCE,
 
 DTYPES = [orc.I8, orc.U8, orc.I32, orc.U32, orc.I64, orc.U64, orc.F16, orc.F32, orc.F64, orc.BF16, orc.F8E4M3, orc.F8E5M2]
 OPS = [orc.SUM, orc.PROD, orc.MAX, orc.MIN, orc.AVG]
-FIFO = {"RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"}
+FIFO = {"RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0", "NCCL_PROTO": None}
 CONFIGS = [
     ("all-pairs FIFOs", {"NCCL_ALGO": "Direct", **FIFO}, (COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_REDUCE)),
     ("ring", {"NCCL_ALGO": "Ring", **FIFO}, (COLL_ALLREDUCE, COLL_REDUCESCATTER)),
     ("chain", {"NCCL_ALGO": "Tree", **FIFO}, (COLL_ALLREDUCE,)),
-    ("default choice", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
+    ("default choice", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None, "NCCL_PROTO": None},
      (COLL_ALLREDUCE, COLL_REDUCESCATTER)),
     # small payloads: the low-latency line protocol (and whatever the planner picks for the other collectives there)
-    ("default choice, 160 KiB", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
+    ("default choice, 160 KiB", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None, "NCCL_PROTO": None},
      (COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_REDUCE), 160 << 10),
+    # NCCL_ALGO=Tree with NCCL_PROTO=LL: the line protocol along the chain
+    ("chain of lines, 160 KiB", {"NCCL_ALGO": "Tree", "NCCL_PROTO": "LL", "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
+     (COLL_ALLREDUCE,), 160 << 10),
 ]
 NAMES = {COLL_ALLREDUCE: "all-reduce", COLL_REDUCESCATTER: "reduce-scatter", COLL_REDUCE: "reduce",
          COLL_ALLGATHER: "all-gather", COLL_BROADCAST: "broadcast"}
