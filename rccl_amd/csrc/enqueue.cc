@@ -346,11 +346,14 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
   // becomes (same result on every rank, rank-order fold).
   // NCCL_ALGO=Tree with NCCL_PROTO=LL: an all-reduce of up to RA_LL_DEFAULT_BYTES (its presence tokens sit beyond that
   // in the line buffers) runs the line protocol along the chain (raLLChainKernel), folded in the chain's order.
+  // NCCL_ALGO=Ring with NCCL_PROTO=LL: the same around the ring (raLLRingKernel), one round of n pieces.
   const bool chainLL = allowLL == 2 && algo == RA_ALGO_TREE && coll == RA_COLL_ALLREDUCE && n <= RA_MAX_RANKS;
-  if (chainLL && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
+  const bool ringLL = allowLL == 2 && algo == RA_ALGO_RING && coll == RA_COLL_ALLREDUCE && n <= RA_MAX_RANKS;
+  if ((chainLL || ringLL) && llMax > (size_t)RA_LL_DEFAULT_BYTES) llMax = (size_t)RA_LL_DEFAULT_BYTES;
   if (allowLL && (algo == RA_ALGO_DIRECT || allowLL == 2) && n > 1 && count * es <= llMax) {
-    p->algo = chainLL ? RA_ALGO_TREE : RA_ALGO_DIRECT;
+    p->algo = chainLL ? RA_ALGO_TREE : ringLL ? RA_ALGO_RING : RA_ALGO_DIRECT;
     if (chainLL) { p->chunkElems = count; p->lastChunkElems = count; }
+    if (ringLL) { p->chunkElems = alignUp(divUp(count, (size_t)n), unit); p->lastChunkElems = p->chunkElems; }
     p->proto = 1;
     p->pairRoles = 0;
     p->nChannels = RA_LL_GRID;

@@ -45,7 +45,8 @@ static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int b
 }
 template <int OP>
 static hipError_t llOp(const RaDevComm* comm, const RaWork& w, hipStream_t s) {
-  if (w.algo == RA_ALGO_TREE) hipLaunchKernelGGL((raLLChainKernel<elem_t, OP>), dim3(w.nChannels), dim3(RA_LL_THREADS), 0, s, comm, w);
+  if (w.algo == RA_ALGO_RING) hipLaunchKernelGGL((raLLRingKernel<elem_t, OP>), dim3(w.nChannels), dim3(RA_LL_THREADS), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_TREE) hipLaunchKernelGGL((raLLChainKernel<elem_t, OP>), dim3(w.nChannels), dim3(RA_LL_THREADS), 0, s, comm, w);
   else hipLaunchKernelGGL((raLLAllReduceKernel<elem_t, OP>), dim3(w.nChannels), dim3(RA_LL_THREADS), 0, s, comm, w);
   return hipGetLastError();
 }

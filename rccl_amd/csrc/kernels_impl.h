@@ -1682,6 +1682,108 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLChainKernel(const RaDevComm
   if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
 }
 
+// Waits until the line at lp carries the flag pair (fy, fw).
+__device__ __forceinline__ void llWaitPair(const RaDevComm* comm, const char* lp, uint32_t fy, uint32_t fw, bool& dead, u32x4& line) {
+  line = llLoadLine(lp);
+  if (dead || (line.y == fy && line.w == fw)) return;
+  const uint64_t t0 = wall_clock64();
+  uint32_t spins = 0;
+  do {
+    __builtin_amdgcn_s_sleep(1);
+    line = llLoadLine(lp);
+    if ((++spins & 0xff) == 0) {
+      const bool asked = __hip_atomic_load(comm->abortFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+      if (asked || wall_clock64() - t0 > comm->timeoutTicks) {
+        uint32_t expect = RA_ERR_NONE;
+        __hip_atomic_compare_exchange_strong(comm->errorFlag, &expect, asked ? RA_ERR_ABORTED : RA_ERR_TIMEOUT,
+                                             __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dead = true;
+        return;
+      }
+    }
+  } while (line.y != fy || line.w != fw);
+}
+
+// The line protocol around the ring (NCCL_ALGO=Ring with NCCL_PROTO=LL; role of the reference's LL ring all-reduce,
+// src/device/all_reduce.h:17-199 over prims_ll.h): the payload is cut into n pieces of w.chunkElems elements; piece j is
+// seeded at ring position j+1, every hop folds local (op) received, position j finishes it (the order of ringAllReduce,
+// src/device/all_reduce.h:82-144), and the finished pieces go round once more.  A thread owns the same offsets of every piece on every
+// rank, so there is no barrier: n-1 reducing hops and n-1 copying hops of lines between neighbours.
+// A finished piece lands in the line slots its partial sum used earlier in the same launch (the partial was consumed
+// before the piece could be finished), so finished lines carry the flag pair (epoch, ~epoch) instead of (epoch, epoch).
+// Presence tokens to every peer as in raLLChainKernel.
+template <typename T, int OP>
+__global__ __launch_bounds__(RA_LL_THREADS) void raLLRingKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  const int n = comm->nRanks, r = comm->rank;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
+  uint32_t epoch = comm->llEpoch[blockIdx.x] + 1;
+  if (epoch == 0) epoch = 1;
+  const int buf = (int)(epoch & 1u);
+  const T* in = (const T*)w.send;
+  T* out = (T*)w.recv;
+  const int8_t* order = comm->ringRanks[0];
+  int pos = 0;
+  for (int i = 0; i < n; i++) if (order[i] == r) pos = i;
+  const int next = order[(pos + 1) % n], prev = order[(pos + n - 1) % n];
+  const size_t nUnits = (w.count * sizeof(T) + 7) / 8;
+  const size_t pu = w.chunkElems * sizeof(T) / 8;            // units per piece (pieces are whole 16-byte packs)
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+  const size_t tokenLine = RA_LL_TOKEN_LINE + blockIdx.x;
+  if ((int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line; line.x = 0; line.y = epoch; line.z = 0; line.w = epoch;
+    stSys((u32x4*)(comm->win[threadIdx.x] + raLLOffset(comm->lay, buf, r)) + tokenLine, line);
+  }
+  bool dead = false;
+  const char* mineLines = comm->win[r] + raLLOffset(comm->lay, buf, prev);        // what prev sends me
+  u32x4* nextLines = (u32x4*)(comm->win[next] + raLLOffset(comm->lay, buf, r));   // what I send next
+  auto local = [&](size_t u) {
+    uint64_t v = llLoadUnit<T>(in, u, w.count);
+    if (OP == RA_OP_PREMULSUM) v = llScale<T, true>(v, w.opArg);
+    return v;
+  };
+  // reducing hops: step s sends piece pos-1-s (own input at s = 0, else what the last step folded) and folds piece pos-2-s
+  for (int s = 0; s < n - 1; s++) {
+    const size_t sendBase = (size_t)((pos - 1 - s + 2 * n) % n) * pu, recvBase = (size_t)((pos - 2 - s + 2 * n) % n) * pu;
+    for (size_t o = gtid; o < pu; o += gsize) {
+      if (s == 0 && sendBase + o < nUnits && !dead) {
+        const uint64_t v = local(sendBase + o);
+        u32x4 line; line.x = (uint32_t)v; line.y = epoch; line.z = (uint32_t)(v >> 32); line.w = epoch;
+        stSys(nextLines + sendBase + o, line);
+      }
+      const size_t u = recvBase + o;
+      if (u >= nUnits) continue;
+      u32x4 line;
+      llWaitPair(comm, mineLines + u * 16, epoch, epoch, dead, line);
+      if (dead) continue;
+      uint64_t v = llRed<T, OP>(local(u), (uint64_t)line.x | ((uint64_t)line.z << 32));
+      const bool last = s == n - 2;                      // piece pos is finished here
+      if (last && OP == RA_OP_SUMPOSTDIV) v = llScale<T, false>(v, w.opArg);
+      u32x4 o2; o2.x = (uint32_t)v; o2.y = epoch; o2.z = (uint32_t)(v >> 32); o2.w = last ? ~epoch : epoch;
+      stSys(nextLines + u, o2);
+      if (last) llStoreUnit<T>(out, u, w.count, v);
+    }
+  }
+  // copying hops: step t receives finished piece pos-1-t, keeps it and passes it on (the last one stays)
+  for (int t = 0; t < n - 1; t++) {
+    const size_t base = (size_t)((pos - 1 - t + 2 * n) % n) * pu;
+    for (size_t o = gtid; o < pu; o += gsize) {
+      const size_t u = base + o;
+      if (u >= nUnits) continue;
+      u32x4 line;
+      llWaitPair(comm, mineLines + u * 16, epoch, ~epoch, dead, line);
+      if (dead) continue;
+      if (t < n - 2) stSys(nextLines + u, line);
+      llStoreUnit<T>(out, u, w.count, (uint64_t)line.x | ((uint64_t)line.z << 32));
+    }
+  }
+  if ((int)threadIdx.x < n && (int)threadIdx.x != r) {
+    u32x4 line;
+    llWaitLine(comm, comm->win[r] + raLLOffset(comm->lay, buf, (int)threadIdx.x) + tokenLine * 16, epoch, dead, line);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) comm->llEpoch[blockIdx.x] = epoch;
+}
+
 // ------------------------------------------------------------------ the all-reduce that allocates nothing
 // Same protocol as raLLAllReduceKernel, all state in the kernel arguments: a.lines[p] is rank p's line array, the
 // lines of sender q for buffer b start at (b * RA_NA_MAX_RANKS + q) * RA_NA_SENDER_BYTES.  Ranks that share a GPU

@@ -382,12 +382,12 @@ def test_low_latency_protocol(bed):
             for o in outs:
                 assert ex.check(dt, o, orc.all_gather_expected(ins), exact=True) is None, (dt, count)
     # NCCL_PROTO=LL asked for by name together with NCCL_ALGO=Tree|Ring (the reference's LL tree / LL ring,
-    # src/device/all_reduce.h:358-551): under Tree small payloads run the line protocol ALONG THE CHAIN (folded in the
-    # chain's order, like the FIFO chain), under Ring they take the one-hop line protocol; larger ones keep the named schedule
+    # src/device/all_reduce.h:17-199,358-551): small all-reduces run the line protocol ALONG THE CHAIN / AROUND THE RING,
+    # folded in that schedule's order like its FIFO form; larger ones keep the FIFOs
     for algo in ("Tree", "Ring"):
         bed.init_comms({"NCCL_ALGO": algo, "NCCL_PROTO": "LL"})
         plan = bed.plan(COLL_ALLREDUCE, 1250, orc.I32)
-        assert plan["proto"] == 1 and plan["algo"] == (ex.ALGO_TREE if algo == "Tree" else ex.ALGO_DIRECT), plan
+        assert plan["proto"] == 1 and plan["algo"] == ALGOS[algo], plan
         assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["algo"] == ALGOS[algo]
         assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] == 0
         _check_allreduce(bed, orc.I32, orc.SUM, 1250)

@@ -93,15 +93,17 @@ def test_protocol_choice_by_size():
         assert proto(AG, 256 * K) == 1 and proto(AG, M) == 2 and proto(AG, 4 * M) == 0
         # rooted collectives: line protocol or FIFO
         assert proto(BC, 64 * K) == 1 and proto(BC, 2 * M) == 0 and proto(RD, 64 * K) == 1 and proto(RD, 2 * M) == 0
-        # ring / tree: FIFO, unless NCCL_PROTO=LL was asked for by name: then small all-reduces under Tree run the line
-        # protocol along the chain (up to 512 KiB, the plan keeps the Tree schedule), under Ring they take the line
+        # ring / tree: FIFO, unless NCCL_PROTO=LL was asked for by name: then all-reduces of up to 512 KiB run the line
+        # protocol along the chain / around the ring (the plan keeps the schedule); the other collectives take the line
         # protocol on the all-pairs links, and the plan says so
         for algo in (1, 2):
             assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, one_shot_max_bytes=lim[n]) == (algo, 0)
-            assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (2 if algo == 2 else 0, 1)
+            assert ra.plan_proto_for_config(n, AR, 1000, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (algo, 1)
             assert ra.plan_proto_for_config(n, AR, 1 << 24, f32, algo=algo, allow_ll=2, one_shot_max_bytes=lim[n]) == (algo, 0)
         assert ra.plan_proto_for_config(n, AR, 512 * K // 4, f32, algo=2, allow_ll=2, one_shot_max_bytes=lim[n]) == (2, 1)
         assert ra.plan_proto_for_config(n, AR, 512 * K // 4 + 1, f32, algo=2, allow_ll=2, one_shot_max_bytes=lim[n]) == (2, 0)
+        assert ra.plan_proto_for_config(n, AR, 512 * K // 4, f32, algo=1, allow_ll=2, one_shot_max_bytes=lim[n]) == (1, 1)
+        assert ra.plan_proto_for_config(n, AR, 512 * K // 4 + 1, f32, algo=1, allow_ll=2, one_shot_max_bytes=lim[n]) == (1, 0)
         assert ra.plan_proto_for_config(n, RS, 1000, f32, algo=2, allow_ll=2, one_shot_max_bytes=lim[n]) == (0, 1)   # no chain for these
     # two exchanges take over above the one-exchange limit, for more than two ranks
     for n in (4, 8):

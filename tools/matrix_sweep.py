@@ -39,6 +39,8 @@ CONFIGS = [
     # NCCL_ALGO=Tree with NCCL_PROTO=LL: the line protocol along the chain
     ("chain of lines, 160 KiB", {"NCCL_ALGO": "Tree", "NCCL_PROTO": "LL", "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
      (COLL_ALLREDUCE,), 160 << 10),
+    ("ring of lines, 160 KiB", {"NCCL_ALGO": "Ring", "NCCL_PROTO": "LL", "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None},
+     (COLL_ALLREDUCE,), 160 << 10),
 ]
 NAMES = {COLL_ALLREDUCE: "all-reduce", COLL_REDUCESCATTER: "reduce-scatter", COLL_REDUCE: "reduce",
          COLL_ALLGATHER: "all-gather", COLL_BROADCAST: "broadcast"}
