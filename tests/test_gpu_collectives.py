@@ -397,6 +397,15 @@ def test_low_latency_protocol(bed):
         _check_allreduce(bed, orc.F16, orc.AVG, 70001)
         _check_allreduce(bed, orc.I8, orc.AVG, 30003, in_place=True)
         _check_allreduce(bed, orc.F8E4M3, orc.MAX, 12888)
+        # a user pre-multiply by scalars that are not powers of two: the product and the sum behind it round separately
+        # (a fused multiply-add would differ in the last bit), folded in the schedule's order
+        count = 30011
+        ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+        scal = [np.float32(1.0 / (r + 3)) for r in range(n)]
+        outs = bed.run(COLL_ALLREDUCE, orc.F32, orc.SUM, count, ins, count * 4, premul=[s_.tobytes() for s_ in scal])
+        want = ex.allreduce(orc.F32, orc.SUM, [a * s_ for a, s_ in zip(ins, scal)], bed.plan(COLL_ALLREDUCE, count, orc.F32))
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want) is None, (algo, r, ex.check(orc.F32, outs[r], want))
         # launches of the chain's lines and of the one-hop lines share buffers and launch counters: alternate them
         for count in (5000, 3, 70000):
             _check_allreduce(bed, orc.F32, orc.SUM, count)
