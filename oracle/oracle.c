@@ -207,7 +207,7 @@ static inline uint8_t op_f8b(int op, uint8_t a, uint8_t b) { return f8_encode(op
 
 /* acc[i] = acc[i] (op) in[i] — one hop of any fold.  op is Sum/Prod/Max/Min. */
 int orc_reduce_into(int dt, int op, size_t n, void* acc, const void* in) {
-#define LOOP(T, F) { T* a = (T*)acc; const T* b = (const T*)in; for (size_t i = 0; i < n; i++) a[i] = F(op, a[i], b[i]); } break
+#define LOOP(T, F) { T* a = (T*)acc; const T* b = (const T*)in; _Pragma("omp parallel for schedule(static) if(n > 65536)") for (size_t i = 0; i < n; i++) a[i] = F(op, a[i], b[i]); } break
   switch (dt) {
     case DT_I8:  LOOP(i8, op_i8);
     case DT_U8:  LOOP(u8, op_u8);
@@ -230,7 +230,7 @@ int orc_reduce_into(int dt, int op, size_t n, void* acc, const void* in) {
 /* acc[i] = in[i] (op) acc[i] — the device's hop: local input is source 0, the
  * received partial is source 1 (prims_simple.h:229,133-134; common_kernel.h:81-133). */
 static int reduce_local_first(int dt, int op, size_t n, void* acc, const void* in) {
-#define LOOP(T, F) { T* a = (T*)acc; const T* b = (const T*)in; for (size_t i = 0; i < n; i++) a[i] = F(op, b[i], a[i]); } break
+#define LOOP(T, F) { T* a = (T*)acc; const T* b = (const T*)in; _Pragma("omp parallel for schedule(static) if(n > 65536)") for (size_t i = 0; i < n; i++) a[i] = F(op, b[i], a[i]); } break
   switch (dt) {
     case DT_I8:  LOOP(i8, op_i8);
     case DT_U8:  LOOP(u8, op_u8);
@@ -253,6 +253,8 @@ static int reduce_local_first(int dt, int op, size_t n, void* acc, const void* i
 /* Host test-oracle average: sum, then divide every element by nranks
  * (test/common/PtrUnion.cpp:285-311; half/bf16 divide in float then narrow). */
 int orc_divide_by_int(int dt, size_t n, void* buf, int d) {
+  if (orc_type_size(dt) == 0) return -1;
+#pragma omp parallel for schedule(static) if(n > 65536)
   for (size_t i = 0; i < n; i++) {
     switch (dt) {
       case DT_I8:  ((i8*)buf)[i]  = (i8)(((i8*)buf)[i] / d); break;
@@ -267,7 +269,7 @@ int orc_divide_by_int(int dt, size_t n, void* buf, int d) {
       case DT_BF16:((uint16_t*)buf)[i] = orc_f32_to_bf16(orc_bf16_to_f32(((uint16_t*)buf)[i]) / d); break;
       case DT_F8E4M3: ((uint8_t*)buf)[i] = f8_encode(f8_decode(((uint8_t*)buf)[i], 3) / d, 3); break;
       case DT_F8E5M2: ((uint8_t*)buf)[i] = f8_encode(f8_decode(((uint8_t*)buf)[i], 2) / d, 2); break;
-      default: return -1;
+      default: break;
     }
   }
   return 0;
@@ -281,11 +283,13 @@ int orc_divide_by_int(int dt, size_t n, void* buf, int d) {
  * src/enqueue.cc:2013-2040).                                                */
 int orc_premul(int dt, size_t n, void* buf, int nranks) {
   switch (dt) {
-    case DT_F32: { float s = (float)(1.0 / nranks); float* p = buf; for (size_t i = 0; i < n; i++) p[i] = p[i] * s; } break;
-    case DT_F64: { double s = 1.0 / nranks; double* p = buf; for (size_t i = 0; i < n; i++) p[i] = p[i] * s; } break;
+    case DT_F32: { float s = (float)(1.0 / nranks); float* p = buf; _Pragma("omp parallel for schedule(static) if(n > 65536)") for (size_t i = 0; i < n; i++) p[i] = p[i] * s; } break;
+    case DT_F64: { double s = 1.0 / nranks; double* p = buf; _Pragma("omp parallel for schedule(static) if(n > 65536)") for (size_t i = 0; i < n; i++) p[i] = p[i] * s; } break;
     case DT_F16: { float s = orc_f16_to_f32(orc_f32_to_f16((float)(1.0 / nranks))); uint16_t* p = buf;
+                   _Pragma("omp parallel for schedule(static) if(n > 65536)")
                    for (size_t i = 0; i < n; i++) p[i] = orc_f32_to_f16(orc_f16_to_f32(p[i]) * s); } break;
     case DT_BF16:{ float s = orc_bf16_to_f32(orc_f32_to_bf16((float)(1.0 / nranks))); uint16_t* p = buf;
+                   _Pragma("omp parallel for schedule(static) if(n > 65536)")
                    for (size_t i = 0; i < n; i++) p[i] = orc_f32_to_bf16(orc_bf16_to_f32(p[i]) * s); } break;
     case DT_F8E4M3: { float s = f8_decode(f8_encode((float)(1.0 / nranks), 3), 3); uint8_t* p = buf;
                       for (size_t i = 0; i < n; i++) p[i] = f8_encode(f8_decode(p[i], 3) * s, 3); } break;
@@ -402,6 +406,59 @@ long orc_first_mismatch(int dt, size_t n, const void* got, const void* want) {
     if (!ok) return (long)i;
   }
   return -1;
+}
+
+/* ---- synthetic buckets for runs at full size --------------------------------
+ * Not part of the reference: its pattern above repeats every 256 elements, so a piece that lands a multiple of 256
+ * elements away from its place would go unnoticed.  Here element i of rank r is a hash of (seed, r, i), which lets any
+ * process produce any rank's bucket (or any slice of it: `first`) without moving it, and every value sits on a grid the
+ * element type holds exactly (k / 2^b in [-1, 1); bf16: [-1/4, 1/4)), so sums round and the association order shows in the bits.       */
+static inline uint64_t orc_hash64(uint64_t i, uint32_t rank, uint32_t seed) {
+  uint64_t z = i + 0x9E3779B97F4A7C15ull * ((uint64_t)rank + 1) + ((uint64_t)seed << 32);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+int orc_fill_hashed(int dt, size_t n, size_t first, int rank, uint32_t seed, void* out) {
+  if (orc_type_size(dt) == 0) return -1;
+#pragma omp parallel for schedule(static) if(n > 65536)
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t h = orc_hash64(first + i, (uint32_t)rank, seed);
+    switch (dt) {
+      case DT_I8: case DT_U8: ((uint8_t*)out)[i] = (uint8_t)h; break;
+      case DT_I32: case DT_U32: ((uint32_t*)out)[i] = (uint32_t)h; break;
+      case DT_I64: case DT_U64: ((uint64_t*)out)[i] = h; break;
+      case DT_F32: ((float*)out)[i] = (float)((int32_t)(h & 0xffffffu) - 0x800000) * (1.0f / 8388608.0f); break;
+      case DT_F64: ((double*)out)[i] = (double)((int64_t)(h & 0xffffffffull) - 0x80000000ll) * (1.0 / 2147483648.0); break;
+      case DT_F16: ((uint16_t*)out)[i] = orc_f32_to_f16((float)((int32_t)(h & 0x7ffu) - 1024) * (1.0f / 1024.0f)); break;
+      case DT_BF16: ((uint16_t*)out)[i] = orc_f32_to_bf16((float)((int32_t)(h & 0xffu) - 128) * (1.0f / 512.0f)); break;   /* [-1/4, 1/4): an 8-way sum stays below 2, so any two association orders stay within the reference's 9e-2 */
+      default: { uint8_t c = (uint8_t)h; ((uint8_t*)out)[i] = c == 0x80 ? 0 : c; } break;    /* 8-bit floats: any code but NaN */
+    }
+  }
+  return 0;
+}
+
+/* Elements outside the reference's tolerance (see orc_first_mismatch); *first gets the lowest such index. */
+long orc_count_mismatch(int dt, size_t n, const void* got, const void* want, long* first) {
+  long bad = 0, lowest = -1;
+  const size_t block = 1u << 20;
+  const size_t nblocks = (n + block - 1) / block;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+  for (size_t b = 0; b < nblocks; b++) {
+    const size_t lo = b * block, len = lo + block < n ? block : n - lo;
+    const size_t es = orc_type_size(dt);
+    size_t at = 0;
+    while (at < len) {
+      long k = orc_first_mismatch(dt, len - at, (const char*)got + (lo + at) * es, (const char*)want + (lo + at) * es);
+      if (k < 0) break;
+      bad++;
+#pragma omp critical
+      { if (lowest < 0 || (long)(lo + at) + k < lowest) lowest = (long)(lo + at) + k; }
+      at += (size_t)k + 1;
+    }
+  }
+  if (first) *first = lowest;
+  return bad;
 }
 
 /* ---- CPU baseline: OpenMP element-wise sum of n fp32 buffers -------------

@@ -55,6 +55,9 @@ def lib():
         L.orc_chain_allreduce.argtypes = [ci, ci, ci, sz, ctypes.POINTER(vp), ctypes.POINTER(ci), vp]
         L.orc_first_mismatch.restype = ctypes.c_long
         L.orc_first_mismatch.argtypes = [ci, sz, vp, vp]
+        L.orc_fill_hashed.argtypes = [ci, sz, sz, ci, ctypes.c_uint32, vp]
+        L.orc_count_mismatch.restype = ctypes.c_long
+        L.orc_count_mismatch.argtypes = [ci, sz, vp, vp, ctypes.POINTER(ctypes.c_long)]
         L.orc_omp_sum_f32.argtypes = [ci, ctypes.POINTER(vp), vp, sz]
         L.orc_ref_style_sum_f32.argtypes = [ci, ctypes.POINTER(vp), vp, sz]
         L.orc_omp_threads.restype = ci
@@ -103,6 +106,24 @@ def fill_pattern(dt, n, rank):
     out = empty(dt, n)
     _check(lib().orc_fill_pattern(dt, n, rank, _ptr(out)), "fill_pattern")
     return out
+
+
+def fill_hashed(dt, n, rank, seed, first=0):
+    """Synthetic bucket for runs at full size: element first+i of `rank` is a hash of (seed, rank, first+i) on a grid the
+    element type holds exactly (not a reference pattern: see orc_fill_hashed)."""
+    out = empty(dt, n)
+    _check(lib().orc_fill_hashed(dt, n, first, rank, seed, _ptr(out)), "fill_hashed")
+    return out
+
+
+def count_mismatch(dt, got, want):
+    """(elements outside the reference tolerance, index of the first one or -1)."""
+    got = np.ascontiguousarray(got)
+    want = np.ascontiguousarray(want)
+    assert got.size == want.size and got.dtype.itemsize == want.dtype.itemsize
+    first = ctypes.c_long(-1)
+    bad = int(lib().orc_count_mismatch(dt, got.size, _ptr(got), _ptr(want), ctypes.byref(first)))
+    return bad, int(first.value)
 
 
 def host_fold(dt, op, inputs):

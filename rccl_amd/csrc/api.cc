@@ -62,7 +62,7 @@ RA_API ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId 
 RA_API ncclResult_t ncclCommInitAll(ncclComm_t* comm, int ndev, const int* devlist) { return raCommInitAll(comm, ndev, devlist); }
 
 RA_API ncclResult_t ncclCommFinalize(ncclComm_t comm) {
-  RA_CHECK(raCommCheck(comm, "ncclCommFinalize"));
+  RA_CHECK(raCommEnsureReady(comm, "ncclCommFinalize"));
   if (comm->haveLast) {
     int old = 0;
     (void)hipGetDevice(&old);
@@ -108,15 +108,15 @@ RA_API ncclResult_t ncclMemAlloc(void** ptr, size_t size) { return raMemAlloc(pt
 RA_API ncclResult_t ncclMemFree(void* ptr) { return raMemFree(ptr); }
 
 RA_API ncclResult_t ncclCommRegister(const ncclComm_t comm, void* buff, size_t size, void** handle) {
-  RA_CHECK(raCommCheck(comm, "ncclCommRegister"));       // src/register.cc:154-160
+  RA_CHECK(raCommEnsureReady(comm, "ncclCommRegister"));       // src/register.cc:154-160
   return raRegRegister(comm, buff, size, handle);
 }
 RA_API ncclResult_t ncclCommDeregister(const ncclComm_t comm, void* handle) {
-  RA_CHECK(raCommCheck(comm, "ncclCommDeregister"));
+  RA_CHECK(raCommEnsureReady(comm, "ncclCommDeregister"));
   return raRegDeregister(comm, handle);
 }
 RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t* fifoPieces) {
-  RA_CHECK(raCommCheck(comm, "rcclAmdCommStats"));
+  RA_CHECK(raCommEnsureReady(comm, "rcclAmdCommStats"));
   uint64_t v[2] = {0, 0};
   if (comm->stats) {
     int old = 0;
@@ -132,7 +132,7 @@ RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, ui
 }
 
 RA_API ncclResult_t rcclAmdCommStepTimers(ncclComm_t comm, uint64_t* ticks) {
-  RA_CHECK(raCommCheck(comm, "rcclAmdCommStepTimers"));
+  RA_CHECK(raCommEnsureReady(comm, "rcclAmdCommStepTimers"));
   if (!ticks) return ncclInvalidArgument;
   memset(ticks, 0, 15 * sizeof(uint64_t));
   if (comm->stats) {
@@ -149,7 +149,7 @@ RA_API ncclResult_t rcclAmdCommStepTimers(ncclComm_t comm, uint64_t* ticks) {
 RA_API ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, ncclDataType_t datatype,
                                              ncclScalarResidence_t residence, ncclComm_t comm) {
   // src/enqueue.cc:2219-2270
-  RA_CHECK(raCommCheck(comm, "ncclRedOpCreatePreMulSum"));
+  RA_CHECK(raCommEnsureReady(comm, "ncclRedOpCreatePreMulSum"));
   if (!op || !scalar) return ncclInvalidArgument;
   const size_t es = raTypeSize(datatype);
   if (es == 0) { RA_WARN("ncclRedOpCreatePreMulSum: unsupported datatype %d", datatype); return ncclInvalidArgument; }
@@ -166,7 +166,7 @@ RA_API ncclResult_t ncclRedOpCreatePreMulSum(ncclRedOp_t* op, void* scalar, nccl
   return ncclInvalidUsage;
 }
 RA_API ncclResult_t ncclRedOpDestroy(ncclRedOp_t op, ncclComm_t comm) {
-  RA_CHECK(raCommCheck(comm, "ncclRedOpDestroy"));
+  RA_CHECK(raCommEnsureReady(comm, "ncclRedOpDestroy"));
   const int ix = (int)op - (int)ncclNumOps;
   if (ix < 0 || ix >= RA_MAX_USER_OPS || !comm->userOps[ix].used) { RA_WARN("ncclRedOpDestroy: operator %d is not a live custom operator", (int)op); return ncclInvalidArgument; }
   comm->userOps[ix].used = false;
@@ -299,7 +299,7 @@ RA_API ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* 
 
 RA_API ncclResult_t rcclAmdPlanInfo(ncclComm_t comm, int coll, size_t count, ncclDataType_t datatype, int* algo, int* proto,
                                     int* nChannels, size_t* chunkElems) {
-  RA_CHECK(raCommCheck(comm, "rcclAmdPlanInfo"));
+  RA_CHECK(raCommEnsureReady(comm, "rcclAmdPlanInfo"));
   if (coll < 0 || coll >= RA_NUM_COLLS) return ncclInvalidArgument;
   RaPlan p;
   RA_CHECK(raPlan(comm, coll, count, datatype, &p));

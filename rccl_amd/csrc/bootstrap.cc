@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <random>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -182,7 +183,10 @@ ncclResult_t RaBootstrap::connect(const ncclUniqueId& id, int rank_, int nRanks_
   if (p.magic != kMagic) { RA_WARN("bootstrap: the ncclUniqueId was not produced by ncclGetUniqueId"); return ncclInvalidArgument; }
   rank = rank_; nRanks = nRanks_;
   if (cancelled.load()) return ncclSystemError;
-  fd = ::socket(AF_INET, SOCK_STREAM, 0);
+  {
+    std::lock_guard<std::mutex> g(fdMutex);
+    fd = ::socket(AF_INET, SOCK_STREAM, 0);
+  }
   if (fd < 0) return ncclSystemError;
   setTimeouts(fd);
   struct sockaddr_in sa; memset(&sa, 0, sizeof sa);
@@ -214,11 +218,12 @@ ncclResult_t RaBootstrap::allGather(const void* mine, void* all, size_t bytes) {
 ncclResult_t RaBootstrap::barrier() { return allGather(nullptr, nullptr, 0); }
 
 void RaBootstrap::close() {
+  std::lock_guard<std::mutex> g(fdMutex);
   if (fd >= 0) { ::close(fd); fd = -1; }
 }
 
 void RaBootstrap::interrupt() {
   cancelled.store(true);
-  const int f = fd;
-  if (f >= 0) ::shutdown(f, SHUT_RDWR);
+  std::lock_guard<std::mutex> g(fdMutex);
+  if (fd >= 0) ::shutdown(fd, SHUT_RDWR);
 }

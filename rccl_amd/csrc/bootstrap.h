@@ -8,12 +8,15 @@
 // concatenation to everyone.
 #pragma once
 #include <atomic>
+#include <mutex>
 #include <stddef.h>
 #include <stdint.h>
 #include "rccl_amd.h"
 
 struct RaBootstrap {
   int fd = -1;
+  std::mutex fdMutex;                   // close() and interrupt() may run on different threads: the descriptor is opened,
+                                        // shut down and closed under this lock, so interrupt() never touches a reused number
   std::atomic<bool> cancelled{false};   // set by interrupt(): every wait of this connection gives up
   int rank = 0, nRanks = 0;
   // Connect to the endpoint encoded in `id`.  Blocks until all nRanks have joined.

@@ -325,6 +325,19 @@ ncclResult_t raCommCheck(const ncclComm* comm, const char* what) {
   return ncclSuccess;
 }
 
+// src/init.cc ncclCommEnsureReady: an entry point that touches what the set-up builds (window layout, device tables,
+// registration state) refuses a communicator whose non-blocking creation has not ended, or has failed.
+ncclResult_t raCommEnsureReady(const ncclComm* comm, const char* what) {
+  RA_CHECK(raCommCheck(comm, what));
+  const int init = comm->initState.load(std::memory_order_acquire);
+  if (init == ncclInProgress) {
+    RA_WARN("%s: attempt to use the communicator before its creation returned ncclSuccess", what);
+    return ncclInvalidArgument;
+  }
+  if (init != ncclSuccess) { RA_WARN("%s: the communicator's creation failed", what); return (ncclResult_t)init; }
+  return ncclSuccess;
+}
+
 ncclResult_t raCommPollError(ncclComm* c) {
   const int init = c->initState.load(std::memory_order_acquire);
   if (init != ncclSuccess) return (ncclResult_t)init;      // still being set up (ncclInProgress), or the set-up failed

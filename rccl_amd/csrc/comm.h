@@ -108,6 +108,7 @@ ncclResult_t raCommSplit(ncclComm_t comm, int color, int key, ncclComm_t* newcom
 ncclResult_t raCommDestroy(ncclComm_t comm, bool abort);
 ncclResult_t raCommCheck(const ncclComm* comm, const char* what);
 ncclResult_t raCommPollError(ncclComm* comm);
+ncclResult_t raCommEnsureReady(const ncclComm* comm, const char* what);   // raCommCheck + the creation has ended well
 
 // enqueue.cc
 struct RaPlan {

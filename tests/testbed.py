@@ -308,6 +308,65 @@ def _child(rank, nranks, device, conn, env):
                 else:
                     res = res[:a["out_bytes"]]
                 conn.send(("ok", (err, res.tobytes())))
+            elif cmd == "big":
+                # A collective at full size.  args: dict(coll, dtype, op, count, seed, in_place, want(path|None), host(path|None)).
+                # The bucket is made here from the oracle's hash pattern (element i of rank r depends on (seed, r, i) only),
+                # nothing large crosses the pipe: the whole output is compared here, bit for bit, with the expectation the
+                # parent computed with the oracle and saved (`want`; all-gather: built here from the same pattern), and
+                # within the reference tolerance with the reference's host fold (`host`).
+                import oracle as orc
+                a = args
+                dt, cnt, seed = a["dtype"], a["count"], a["seed"]
+                es = ra.TYPE_SIZE[dt]
+                n_in = cnt * (nranks if a["coll"] == COLL_REDUCESCATTER else 1)
+                n_out = cnt * (nranks if a["coll"] == COLL_ALLGATHER else 1)
+                GUARD = 256
+                host_in = orc.fill_hashed(dt, n_in, rank, seed).view(np.uint8)
+                out = torch.full((n_out * es + GUARD,), 0xA5, dtype=torch.uint8, device="cuda")
+                if a.get("in_place"):
+                    assert a["coll"] == COLL_ALLREDUCE
+                    out[:n_in * es].copy_(torch.from_numpy(host_in))
+                    inp = out
+                else:
+                    inp = torch.from_numpy(host_in).cuda()
+                del host_in
+                torch.cuda.synchronize()
+                with torch.cuda.stream(stream):
+                    if a["coll"] == COLL_ALLREDUCE:
+                        comm.all_reduce(inp.data_ptr(), out.data_ptr(), cnt, dt, a["op"], stream)
+                    elif a["coll"] == COLL_REDUCESCATTER:
+                        comm.reduce_scatter(inp.data_ptr(), out.data_ptr(), cnt, dt, a["op"], stream)
+                    else:
+                        comm.all_gather(inp.data_ptr(), out.data_ptr(), cnt, dt, stream)
+                stream.synchronize()
+                err = comm.async_error()
+                res = out.cpu().numpy()
+                del inp, out
+                torch.cuda.empty_cache()
+                report = {"err": err, "guard_ok": bool(np.all(res[n_out * es:] == 0xA5)), "bad": 0, "first": -1, "host_bad": 0,
+                          "host_first": -1, "elems": n_out}
+                got = res[:n_out * es].view(orc.NP_OF[dt])
+                if a["coll"] == COLL_ALLGATHER:
+                    for q in range(nranks):
+                        blk = orc.fill_hashed(dt, cnt, q, seed)
+                        diff = np.nonzero(got[q * cnt:(q + 1) * cnt].view(np.uint8) != blk.view(np.uint8))[0]
+                        if diff.size:
+                            report["bad"] += int(diff.size)
+                            if report["first"] < 0:
+                                report["first"] = q * cnt + int(diff[0]) // es
+                else:
+                    lo = rank * cnt if a["coll"] == COLL_REDUCESCATTER else 0
+                    bits = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[es]
+                    want = np.load(a["want"], mmap_mode="r")[lo:lo + n_out]
+                    same = np.array_equal(got.view(bits), want.view(bits))
+                    diff = np.empty(0, dtype=np.int64) if same else np.nonzero(got.view(bits) != want.view(bits))[0]
+                    if diff.size:
+                        report["bad"], report["first"] = int(diff.size), int(diff[0])
+                        report["got"], report["want"] = got[diff[:4]].tolist(), np.asarray(want[diff[:4]]).tolist()
+                    if a.get("host"):
+                        host = np.load(a["host"], mmap_mode="r")[lo:lo + n_out]
+                        report["host_bad"], report["host_first"] = orc.count_mismatch(dt, got, np.ascontiguousarray(host))
+                conn.send(("ok", report))
             elif cmd == "reg_prepare":
                 # args: dict(coll, dtype, count, input(bytes), in_place, register_recv, fine): buffers that stay alive across
                 # commands.  fine: the receive buffer comes from ncclMemAlloc (what peers may write into), else hipMalloc.
@@ -592,6 +651,14 @@ class TestBed:
         for r, (err, _) in enumerate(res):
             assert err == 0, f"rank {r}: asynchronous error {err}"
         return [np.frombuffer(b, dtype=np.uint8) for _, b in res]
+
+    def run_big(self, coll, dtype, op, count, seed, want=None, host=None, in_place=False):
+        """One collective at full size on buckets every rank makes itself from the oracle's hash pattern; every rank
+        compares its whole output with the saved expectation(s) and returns a report dict."""
+        if not self.inited:
+            self.init_comms()
+        return self._all("big", [dict(coll=coll, dtype=dtype, op=op, count=count, seed=seed, want=want, host=host,
+                                      in_place=in_place)] * self.nranks)
 
     def run_registered(self, dtype, op, count, inputs, in_place=False, register_ranks=None, runs=1, coll=COLL_ALLREDUCE,
                        graph=False, fine=True):
