@@ -241,21 +241,39 @@ ncclResult_t rcclAmdReduceCopy(void* dst, const void* const* srcs, int nsrc, siz
  * allocate (code under HIP graph capture rules that forbid hipMalloc, tight serving loops, harnesses that forbid
  * allocation) and therefore cannot create a communicator, whose window ncclCommInitAll / ncclCommInitRank
  * allocate.  Same arithmetic as ncclAllReduce on a communicator made by ncclCommInitAll(devices): rank r's input
- * is sendbuffs[r] on devices[r], its result goes to recvbuffs[r] (may equal sendbuffs[r]), contributions are folded
- * in rank order, so results are bit-identical to ncclAllReduce's.  The kernel of rank r is enqueued on streams[r];
- * the streams must be distinct when ranks share a device (the n kernels wait for one another).
+ * is sendbuffs[r], its result goes to recvbuffs[r] (may equal sendbuffs[r]), contributions are folded in rank
+ * order, so results are bit-identical to ncclAllReduce's.  The kernel of rank r is enqueued on streams[r].
  * The staging lines live in a static 8 MiB array that every GPU the library runs on holds until the process ends.
- * Limits: 1 <= nranks <= 8; count * sizeof(datatype) <= 256 KiB per rank (larger counts return
- * ncclInvalidArgument: use ncclAllReduce); built-in operators only (ncclSum .. ncclAvg); all ranks in this
- * process.  Every call on a GPU uses that GPU's one array: two calls whose kernels could run at the same time on
- * a GPU race, so a call must be ordered (stream order or a synchronisation) after the previous call that
- * involved any of its GPUs has finished on all of that call's GPUs.  A call is not meant to be replayed from a
- * captured graph (each call carries a fresh sequence number in its kernel arguments).  The first call that names
- * a device looks up that device's array (hipGetSymbolAddress) and, between distinct devices, enables peer access;
- * later calls make no HIP calls besides hipSetDevice and the kernel launches. */
+ * Limits:
+ *  - all ranks in this process and ON ONE DEVICE: devices[r] must all be equal, anything else returns
+ *    ncclInvalidUsage.  (The static array is ordinary device memory of the library's code object, which a peer GPU
+ *    must not store into; between devices use ncclAllReduce on a communicator.)
+ *  - 1 <= nranks <= 4 (more than 8 returns ncclInvalidArgument, 5 to 8 ncclInvalidUsage: that many kernels of one
+ *    process do not run at the same time on one device, see the streams below).
+ *  - count * sizeof(datatype) <= 256 KiB per rank (larger counts return ncclInvalidArgument: use ncclAllReduce);
+ *    built-in operators only (ncclSum .. ncclAvg).
+ *  - The n kernels wait for one another, so all of them must be running at once: every rank needs a stream of its
+ *    own (two ranks naming one stream, NULL included, return ncclInvalidUsage), and the streams must sit on different
+ *    hardware queues.  HIP gives a process GPU_MAX_HW_QUEUES (default 4) hardware queues per stream priority and
+ *    deals streams onto them in turn, so up to 2 ranks any two streams will do; for 3 or 4, create the streams with
+ *    hipStreamCreateWithPriority spread over the priority levels.  Ranks whose kernels end up behind one another on one queue wait for their time limit
+ *    (RCCL_AMD_SPIN_TIMEOUT_MS, default 120 s) and leave their receive buffers unwritten.
+ *  - Every call uses the device's one array: two calls whose kernels could run at the same time race, so a call
+ *    must be ordered (stream order or a synchronisation) after the previous call has finished on all its streams.
+ *    A call is not meant to be replayed from a captured graph (it carries a fresh call number in its arguments).
+ * The call returns once the kernels are enqueued.  A kernel that gave up waiting reports through
+ * rcclAmdNoAllocAsyncError; when the launch of one rank fails the ranks already launched are told to leave at once
+ * and the call returns ncclUnhandledCudaError.  The first call on a device looks up that device's arrays
+ * (hipGetSymbolAddress); later calls make no HIP calls besides hipSetDevice and the kernel launches. */
 ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* const* recvbuffs, const int* devices,
                                      int nranks, size_t count, ncclDataType_t datatype, ncclRedOp_t op,
                                      const hipStream_t* streams);
+
+/* Asynchronous result of the rcclAmdAllReduceNoAlloc calls that ran on `device` (the role ncclCommGetAsyncError has for
+ * a communicator): *asyncError = ncclSuccess, or ncclRemoteError once a kernel of such a call gave up waiting for its
+ * peers and left its receive buffer incomplete (sticky).  Synchronous (a 4-byte copy from the device); allocates
+ * nothing. */
+ncclResult_t rcclAmdNoAllocAsyncError(int device, ncclResult_t* asyncError);
 
 /* Ring schedule synthesis for a single node whose GPUs are joined by direct xGMI links
  * (the job of the ring search + pre-baked models, src/graph/search.cc:919-986,
@@ -269,6 +287,19 @@ ncclResult_t rcclAmdTopoRings(int ngpus, const int* adj, int maxRings, int* ring
  * src/graph/xml.cc) and fills the ngpus x ngpus direct-xGMI adjacency matrix.  `adj` must hold
  * maxGpus*maxGpus ints; *ngpus receives the GPU count. */
 ncclResult_t rcclAmdTopoParseXml(const char* xmlText, int maxGpus, int* adj, int* ngpus);
+
+/* Link table -> adjacency (host logic only): linkType / hops are ngpus x ngpus as hipExtGetLinkTypeAndHopCount reports
+ * them (type 4 = xGMI); adj[a][b] = 1 when both directions of the pair are one xGMI hop, the links the reference turns
+ * into <xgmi> edges (src/graph/xml.cc:780-791); *allDirect = 1 when every pair is, which is when the all-pairs schedule
+ * is the default (otherwise the rings over the links that exist are). */
+ncclResult_t rcclAmdTopoFromLinks(int ngpus, const unsigned* linkType, const unsigned* hops, int* adj, int* allDirect);
+
+/* Bytes of the window a communicator of `nranks` ranks allocates per rank for `channels` channels with the default slot
+ * and exchange settings (environment included), after it has been fitted into the size budget
+ * (RCCL_AMD_WINDOW_MAX_BYTES, default 1.5 GiB): total, FIFO storage, exchange region, channels kept.  Host logic only
+ * (cf. the reference's per-connection buffers, src/transport/p2p.cc:447-450, src/init.cc:837-875). */
+ncclResult_t rcclAmdWindowBytesFor(int nranks, int channels, size_t* totalBytes, size_t* fifoBytes, size_t* exchangeBytes,
+                                   int* channelsOut);
 
 /* What the planner would choose for a collective on `comm`: algorithm (0 direct all-pairs,
  * 1 ring, 2 chain tree), protocol (0 simple, 1 low-latency), channels, chunk elements.

@@ -281,6 +281,28 @@ RA_API ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* 
   for (int r = 0; r < nranks; r++) {
     if (devices[r] < 0 || devices[r] >= nDev || devices[r] >= 64) { RA_WARN("rcclAmdAllReduceNoAlloc: rank %d names device %d", r, devices[r]); return ncclInvalidArgument; }
     if (count && (!sendbuffs[r] || !recvbuffs[r])) { RA_WARN("rcclAmdAllReduceNoAlloc: rank %d has a null buffer", r); return ncclInvalidArgument; }
+    // The staging lines are part of the library's code object, which is ordinary (coarse-grained) device memory: a peer
+    // GPU may not store into that (peers write only fine-grained or uncached memory, see reg.h), so every rank of a
+    // call has to be on the same device.
+    if (devices[r] != devices[0]) {
+      RA_WARN("rcclAmdAllReduceNoAlloc: ranks on different devices (%d and %d): all ranks of a call must share one device; "
+              "between devices use ncclAllReduce on a communicator", devices[0], devices[r]);
+      return ncclInvalidUsage;
+    }
+    // The n kernels wait for one another: two ranks on one stream would run one after the other and never meet.
+    for (int q = 0; q < r; q++)
+      if (streams[q] == streams[r]) {
+        RA_WARN("rcclAmdAllReduceNoAlloc: ranks %d and %d name the same stream; every rank needs a stream of its own", q, r);
+        return ncclInvalidUsage;
+      }
+  }
+  // Every rank's kernel waits for the others, so all must be running at once, each on a hardware queue of its own; a
+  // process has few of those per device (GPU_MAX_HW_QUEUES, default 4, per stream priority; 8 ranks of one process on
+  // one device measured: the kernels queue behind one another and run into their time limit).
+  if (nranks > RA_NA_MAX_RANKS_PER_DEVICE) {
+    RA_WARN("rcclAmdAllReduceNoAlloc: %d ranks on device %d; at most %d ranks may share a device (one hardware queue each)",
+            nranks, devices[0], RA_NA_MAX_RANKS_PER_DEVICE);
+    return ncclInvalidUsage;
   }
   if (count == 0) return ncclSuccess;
   int devOp = RA_OP_SUM;
@@ -291,9 +313,34 @@ RA_API ncclResult_t rcclAmdAllReduceNoAlloc(const void* const* sendbuffs, void* 
   long ms = 120000;                                     // the same knob and default as a communicator's waits
   if (const char* t = getenv("RCCL_AMD_SPIN_TIMEOUT_MS")) { if (*t) ms = strtol(t, nullptr, 0); }
   if (ms < 1) ms = 1;
-  hipError_t e = raNoAllocAllReduce(sendbuffs, recvbuffs, devices, nranks, count, datatype, devOp, arg,
+  hipError_t e = raNoAllocAllReduce(sendbuffs, recvbuffs, devices[0], nranks, count, datatype, devOp, arg,
                                     (uint64_t)ms * 100000ull, streams);
   if (e != hipSuccess) { RA_WARN("rcclAmdAllReduceNoAlloc: %s", hipGetErrorString(e)); return ncclUnhandledCudaError; }
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t rcclAmdNoAllocAsyncError(int device, ncclResult_t* asyncError) {
+  if (!asyncError) return ncclInvalidArgument;
+  uint32_t call = 0;
+  hipError_t e = raNoAllocFailedCall(device, &call);
+  if (e != hipSuccess) { RA_WARN("rcclAmdNoAllocAsyncError: %s", hipGetErrorString(e)); return e == hipErrorInvalidDevice ? ncclInvalidArgument : ncclUnhandledCudaError; }
+  if (call) RA_WARN("rcclAmdAllReduceNoAlloc: call %u on device %d gave up waiting for its peers; its receive buffers are incomplete", call, device);
+  *asyncError = call ? ncclRemoteError : ncclSuccess;
+  return ncclSuccess;
+}
+
+// Window a communicator of `nranks` ranks would allocate with `channels` channels and the default slot and exchange
+// settings (environment included), after the fit into the size budget; host logic only.
+RA_API ncclResult_t rcclAmdWindowBytesFor(int nranks, int channels, size_t* totalBytes, size_t* fifoBytes, size_t* exchangeBytes,
+                                          int* channelsOut) {
+  if (nranks < 2 || nranks > RA_MAX_RANKS || channels < 1 || channels > RA_MAX_CHANNELS) return ncclInvalidArgument;
+  RaWindowLayout l;
+  int ch = channels;
+  raWindowLayoutFor(nranks, &ch, &l);
+  if (totalBytes) *totalBytes = l.totalBytes;
+  if (fifoBytes) *fifoBytes = raDataBytes(l);
+  if (exchangeBytes) *exchangeBytes = l.totalBytes - l.osFlagOffset;
+  if (channelsOut) *channelsOut = ch;
   return ncclSuccess;
 }
 

@@ -44,6 +44,32 @@ struct DeviceGuard {
   ~DeviceGuard() { if (old >= 0) (void)hipSetDevice(old); }
 };
 
+// Limits of the one-exchange and two-exchange all-reduce protocols for this group size.
+void exchangeLimits(ncclComm* c) {
+  // One-exchange all-reduce (enqueue.cc, proto 2): it sends (n-1) x S per rank instead of 2(n-1)/n x S, so the default
+  // limit follows the group size: with two ranks the link bytes are the same and only HBM traffic grows (5 S against
+  // 4 S per rank), with four they double, with eight they are four times as many.  Priced against one xGMI link per
+  // peer (about 120 GB/s achievable) and the roughly 30 us the two extra flag-synchronised phases of the three-phase
+  // schedule cost, the break-even is near 7 MB at four ranks and 5 MB at eight; the defaults stay below that (4 MiB,
+  // 2 MiB).  With ranks sharing one GPU (no links, HBM only) one exchange measured faster up to 16 MiB at four ranks
+  // and 8 MiB at eight (tools/oneshot_limits.sh).
+  {
+    const long dflt = c->nRanks == 2 ? (64L << 20) : c->nRanks <= 4 ? (4L << 20) : (2L << 20);
+    long v = envLong("RCCL_AMD_ONESHOT_MAX_BYTES", dflt);
+    const long most = (256L << 20) / c->nRanks;        // two buffers for every sender: at most 512 MiB of window
+    if (v > most) { RA_INFO("RCCL_AMD_ONESHOT_MAX_BYTES=%ld reduced to %ld (window space)", v, most); v = most; }
+    c->oneShotMaxBytes = v > 0 ? (size_t)v : 0;
+    // Above that, up to RCCL_AMD_TWO_EXCHANGE_MAX_BYTES, an all-reduce of more than two ranks runs as two exchanges:
+    // the link bytes of the three-phase schedule without its FIFOs and credits (gradient-bucket sizes; the default
+    // needs 2 x 2 x 64 MiB of window).  Larger payloads keep the pipelined FIFO schedule, whose phases overlap on the
+    // links; here a workgroup's push, fold and copy follow one another.  With ranks sharing one GPU two exchanges
+    // measured 2.5 times faster at 8 MiB, 1.7 times at 32 MiB and still 1.3 times at 128 MiB (8 ranks).
+    long t = envLong("RCCL_AMD_TWO_EXCHANGE_MAX_BYTES", c->nRanks > 2 ? (64L << 20) : 0);
+    if (t > (128L << 20)) t = 128L << 20;
+    c->twoExMaxBytes = (c->nRanks > 2 && t > 0) ? (size_t)t : 0;
+  }
+}
+
 void readTunables(ncclComm* c) {
   // NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS as in src/graph/connect.cc:521-545; the native
   // knob is RCCL_AMD_NCHANNELS.
@@ -75,28 +101,7 @@ void readTunables(ncclComm* c) {
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
-  // One-exchange all-reduce (enqueue.cc, proto 2): it sends (n-1) x S per rank instead of 2(n-1)/n x S, so the default
-  // limit follows the group size: with two ranks the link bytes are the same and only HBM traffic grows (5 S against
-  // 4 S per rank), with four they double, with eight they are four times as many.  Priced against one xGMI link per
-  // peer (about 120 GB/s achievable) and the roughly 30 us the two extra flag-synchronised phases of the three-phase
-  // schedule cost, the break-even is near 7 MB at four ranks and 5 MB at eight; the defaults stay below that (4 MiB,
-  // 2 MiB).  With ranks sharing one GPU (no links, HBM only) one exchange measured faster up to 16 MiB at four ranks
-  // and 8 MiB at eight (tools/oneshot_limits.sh).
-  {
-    const long dflt = c->nRanks == 2 ? (64L << 20) : c->nRanks <= 4 ? (4L << 20) : (2L << 20);
-    long v = envLong("RCCL_AMD_ONESHOT_MAX_BYTES", dflt);
-    const long most = (256L << 20) / c->nRanks;        // two buffers for every sender: at most 512 MiB of window
-    if (v > most) { RA_INFO("RCCL_AMD_ONESHOT_MAX_BYTES=%ld reduced to %ld (window space)", v, most); v = most; }
-    c->oneShotMaxBytes = v > 0 ? (size_t)v : 0;
-    // Above that, up to RCCL_AMD_TWO_EXCHANGE_MAX_BYTES, an all-reduce of more than two ranks runs as two exchanges:
-    // the link bytes of the three-phase schedule without its FIFOs and credits (gradient-bucket sizes; the default
-    // needs 2 x 2 x 64 MiB of window).  Larger payloads keep the pipelined FIFO schedule, whose phases overlap on the
-    // links; here a workgroup's push, fold and copy follow one another.  With ranks sharing one GPU two exchanges
-    // measured 2.5 times faster at 8 MiB, 1.7 times at 32 MiB and still 1.3 times at 128 MiB (8 ranks).
-    long t = envLong("RCCL_AMD_TWO_EXCHANGE_MAX_BYTES", c->nRanks > 2 ? (64L << 20) : 0);
-    if (t > (128L << 20)) t = 128L << 20;
-    c->twoExMaxBytes = (c->nRanks > 2 && t > 0) ? (size_t)t : 0;
-  }
+  exchangeLimits(c);
   // NCCL_PROTO (src/graph/tuning.cc:476-485): "Simple" keeps small all-reduces off the low-latency path
   const char* pr = getenv("NCCL_PROTO");
   c->allowLL = !(pr && *pr && !strcasestr(pr, "LL"));
@@ -111,31 +116,15 @@ void readTunables(ncclComm* c) {
   }
 }
 
-void makeLayout(ncclComm* c) {
+// Lays the window out for the communicator's channel count, slot geometry and exchange limits.
+void layoutFor(ncclComm* c, long slots, long slotBytes, bool staged) {
   RaWindowLayout& l = c->lay;
   l.nRanks = c->nRanks;
   l.nChannels = c->maxChannels;
-  // Two deep, 768 KiB slots between GPUs: the roles of a channel run in different workgroups, so one slot being
-  // filled while the other is drained is all the overlap there is to have, and a larger step spreads the per-step
-  // costs (measured: 1 GiB all-reduce, ranks sharing one GPU, 4 x 256 KiB -> 2 x 512 KiB: 2.81 -> 2.36 ms at 2 ranks,
-  // 12.4 -> 11.9 ms at 8; 512 KiB -> 768 KiB with the steps of a channel balanced: 1.73 -> 1.68 ms at 2 ranks,
-  // 5.53 -> 5.09 ms at 4, 10.85 -> 10.46 ms at 8; 1 MiB slots are slower again, 1.81 ms at 2 ranks).  Above 8 ranks
-  // 512 KiB, which keeps the window below the 2 GiB an IPC mapping is good for.  The host-staged transport keeps
-  // 4 x 256 KiB: its proxy threads want more steps in flight.
-  const bool staged = raNetRequested() && c->multiProcess;
-  long slots = envLong("RCCL_AMD_NSLOTS", staged ? 4 : 2);
-  if (slots < 2) slots = 2;
-  if (slots > 16) slots = 16;
   l.nSlots = (int)slots;
-  long slotBytes = envLong("RCCL_AMD_SLOT_BYTES", -1);
-  if (slotBytes <= 0) {
-    long buff = envLong("NCCL_BUFFSIZE", -1);      // whole FIFO, as in src/init.cc:837-875
-    slotBytes = buff > 0 ? buff / slots : (staged ? (256 << 10) : c->nRanks <= 8 ? (768 << 10) : (512 << 10));
-  }
-  if (slotBytes < 4096) slotBytes = 4096;
   l.slotBytes = (uint32_t)alignUp((size_t)slotBytes, 4096);
   l.dataOffset = alignUp(raFlagBytes(l), 4096);
-  l.llOffset = alignUp(raDataOffset(l, l.nChannels, 0, 0), 4096);   // one past the last FIFO
+  l.llOffset = alignUp(l.dataOffset + raDataBytes(l), 4096);          // one past the last FIFO
   l.llBytes = (size_t)RA_LL_MAX_BYTES * 2;                          // 16-byte line per 8 bytes of payload
   l.osFlagOffset = alignUp(raLLOffset(l, 2, 0), 4096);
   // one sender's share of a buffer: a whole payload of the one-exchange limit, or two pieces (one per exchange) of
@@ -145,6 +134,48 @@ void makeLayout(ncclComm* c) {
   l.osBytes = staged ? 0 : alignUp(share, 4096);
   l.osDataOffset = l.osFlagOffset + (l.osBytes ? alignUp((size_t)2 * RA_OS_MAX_GRID * l.nRanks * RA_FLAG_STRIDE, 4096) : 0);
   l.totalBytes = raOsDataOffset(l, 2, 0);
+}
+
+void makeLayout(ncclComm* c) {
+  // Two deep, 768 KiB slots between GPUs: the roles of a channel run in different workgroups, so one slot being
+  // filled while the other is drained is all the overlap there is to have, and a larger step spreads the per-step
+  // costs (measured: 1 GiB all-reduce, ranks sharing one GPU, 4 x 256 KiB -> 2 x 512 KiB: 2.81 -> 2.36 ms at 2 ranks,
+  // 12.4 -> 11.9 ms at 8; 512 KiB -> 768 KiB with the steps of a channel balanced: 1.73 -> 1.68 ms at 2 ranks,
+  // 5.53 -> 5.09 ms at 4, 10.85 -> 10.46 ms at 8; 1 MiB slots are slower again, 1.81 ms at 2 ranks).  Above 8 ranks
+  // 512 KiB.  The host-staged transport keeps 4 x 256 KiB: its proxy threads want more steps in flight.
+  const bool staged = raNetRequested() && c->multiProcess;
+  long slots = envLong("RCCL_AMD_NSLOTS", staged ? 4 : 2);
+  if (slots < 2) slots = 2;
+  if (slots > 16) slots = 16;
+  long slotBytes = envLong("RCCL_AMD_SLOT_BYTES", -1);
+  const bool slotsFromEnv = slotBytes > 0 || envLong("NCCL_BUFFSIZE", -1) > 0;
+  if (slotBytes <= 0) {
+    long buff = envLong("NCCL_BUFFSIZE", -1);      // whole FIFO, as in src/init.cc:837-875
+    slotBytes = buff > 0 ? buff / slots : (staged ? (256 << 10) : c->nRanks <= 8 ? (768 << 10) : (512 << 10));
+  }
+  if (slotBytes < 4096) slotBytes = 4096;
+  layoutFor(c, slots, slotBytes, staged);
+  // Head-room.  A window shared between processes has to stay below the 2 GiB an IPC mapping is good for (comm.cc
+  // refuses more), and every communicator of a process holds one, so the default geometry is fitted into a budget
+  // (RCCL_AMD_WINDOW_MAX_BYTES, default 1.5 GiB) whatever channel count was asked for: the two-exchange region
+  // shrinks first (down to 16 MiB payloads), then the one-exchange limit (down to 1 MiB), then the slots in 64 KiB
+  // steps (down to 256 KiB; not when the environment fixed them), last the channels.  Every rank does the same sums.
+  long budget = envLong("RCCL_AMD_WINDOW_MAX_BYTES", 1536L << 20);
+  if (budget > (2047L << 20)) budget = 2047L << 20;
+  if (budget < (64L << 20)) budget = 64L << 20;
+  const size_t before = c->lay.totalBytes;
+  while (c->lay.totalBytes > (size_t)budget) {
+    if (c->twoExMaxBytes > ((size_t)16 << 20)) c->twoExMaxBytes /= 2;
+    else if (c->oneShotMaxBytes > ((size_t)1 << 20)) c->oneShotMaxBytes /= 2;
+    else if (!slotsFromEnv && slotBytes > (256 << 10)) slotBytes -= 64 << 10;
+    else if (c->maxChannels > 8) c->maxChannels--;
+    else break;
+    layoutFor(c, slots, slotBytes, staged);
+  }
+  if (c->lay.totalBytes != before)
+    RA_INFO("rank %d: window fitted into %ld MiB: %zu -> %zu MiB (two-exchange limit %zu MiB, one-exchange limit %zu KiB, "
+            "slots %u KiB, %d channels)", c->rank, budget >> 20, before >> 20, c->lay.totalBytes >> 20, c->twoExMaxBytes >> 20,
+            c->oneShotMaxBytes >> 10, c->lay.slotBytes >> 10, c->maxChannels);
 }
 
 // Low-latency launches use 32 workgroups when every rank has a GPU to itself and 16 when ranks share one (8 ranks x 16
@@ -190,15 +221,21 @@ ncclResult_t allocWindow(ncclComm* c) {
   RA_HIP(hipMemset(p, 0, c->lay.dataOffset));   // all flag words start at zero
   RA_HIP(hipMemset((char*)p + c->lay.llOffset, 0, c->lay.osDataOffset - c->lay.llOffset));   // no line carries a live epoch, no flag is up
   RA_HIP(hipDeviceSynchronize());
-  RA_INFO("rank %d: window %p, %zu MiB (%d channels x %d ranks x %d kinds x %d slots x %u KiB)", c->rank, p,
-          c->lay.totalBytes >> 20, c->lay.nChannels, c->nRanks, RA_NKINDS, c->lay.nSlots, c->lay.slotBytes >> 10);
+  RA_INFO("rank %d: window %p, %zu MiB = flags %zu KiB + FIFOs %zu MiB (%d channels x %d peers x %d kinds x %d slots x %u KiB) "
+          "+ line buffers %zu MiB + exchange region %zu MiB (RCCL_AMD_ONESHOT_MAX_BYTES / RCCL_AMD_TWO_EXCHANGE_MAX_BYTES)",
+          c->rank, p, c->lay.totalBytes >> 20, c->lay.dataOffset >> 10, raDataBytes(c->lay) >> 20, c->lay.nChannels, c->nRanks - 1,
+          RA_NKINDS, c->lay.nSlots, c->lay.slotBytes >> 10, (c->lay.osFlagOffset - c->lay.llOffset) >> 20,
+          (c->lay.totalBytes - c->lay.osFlagOffset) >> 20);
   return ncclSuccess;
 }
 
+// Rings over the links the machine really has (c->linkAdj: 1 where two ranks' GPUs are joined by one xGMI hop, or are
+// the same GPU).  The reference builds its rings from the same facts (src/graph/xml.cc:780-791 -> search.cc:970-986).
 void computeRings(ncclComm* c) {
   const int n = c->nRanks;
   std::vector<int> adj((size_t)n * n, 1);
-  for (int i = 0; i < n; i++) adj[(size_t)i * n + i] = 0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) adj[(size_t)i * n + j] = i == j ? 0 : c->linkAdj[i * RA_MAX_RANKS + j];
   std::vector<std::vector<int>> rings;
   raTopoRings(n, adj.data(), RA_MAX_CHANNELS, rings);
   if (rings.empty()) {
@@ -209,6 +246,21 @@ void computeRings(ncclComm* c) {
   c->nRings = (int)rings.size();
   for (int r = 0; r < c->nRings; r++)
     for (int i = 0; i < n; i++) c->ringRanks[r][i] = (int8_t)rings[(size_t)r][(size_t)i];
+}
+
+// The all-pairs schedule is the default only where every pair of ranks has its own link; otherwise the rings above,
+// which use the links there are, take over (as if NCCL_ALGO=Ring had been set; an explicit NCCL_ALGO stands).
+void chooseDefaultSchedule(ncclComm* c) {
+  const int n = c->nRanks;
+  int missing = 0;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) missing += i != j && !c->linkAdj[i * RA_MAX_RANKS + j];
+  c->allDirect = missing == 0;
+  if (!c->allDirect && c->algoEnv < 0) {
+    RA_WARN("rank %d: %d of %d rank pairs are not joined by a direct xGMI link: the ring schedule over the links that "
+            "exist replaces the all-pairs default (set NCCL_ALGO to choose otherwise)", c->rank, missing / 2, n * (n - 1) / 2);
+    c->algoEnv = RA_ALGO_RING;
+  }
 }
 
 ncclResult_t buildDevComm(ncclComm* c) {
@@ -260,19 +312,21 @@ ncclResult_t buildDevComm(ncclComm* c) {
 // One line per peer about the link that joins the two GPUs (the reference builds its topology from the same
 // facts: xGMI links of one hop become <xgmi> edges, src/graph/xml.cc:780-791).  The all-pairs schedule assumes a
 // direct xGMI link to every peer; anything else still works and is slower, so it is said out loud.
-void describeLink(ncclComm* c, int peerRank, int peerDev) {
-  if (peerDev == c->device) return;
+// Returns 1 when the two GPUs are joined by one xGMI hop (or are one GPU), 0 when they are not, and says so.
+int describeLink(ncclComm* c, int peerRank, int peerDev) {
+  if (peerDev == c->device) return 1;
   uint32_t type = 0, hops = 0;
-  if (hipExtGetLinkTypeAndHopCount(c->device, peerDev, &type, &hops) != hipSuccess) {
+  if (peerDev < 0 || hipExtGetLinkTypeAndHopCount(c->device, peerDev, &type, &hops) != hipSuccess) {
     (void)hipGetLastError();
-    RA_INFO("rank %d (device %d) -> rank %d (device %d): link type unknown", c->rank, c->device, peerRank, peerDev);
-    return;
+    // (a peer whose GPU this process cannot see, or a runtime that does not say: nothing speaks against the link)
+    RA_INFO("rank %d (device %d) -> rank %d (device %d): link type unknown, taken to be direct", c->rank, c->device, peerRank, peerDev);
+    return 1;
   }
-  // HSA_AMD_LINK_INFO_TYPE_XGMI == 4 (hsa_ext_amd.h); hipExtGetLinkTypeAndHopCount reports that enumeration
-  const bool xgmi = type == 4;
-  if (xgmi && hops == 1) RA_INFO("rank %d (device %d) -> rank %d (device %d): xGMI, 1 hop", c->rank, c->device, peerRank, peerDev);
-  else RA_WARN("rank %d (device %d) -> rank %d (device %d): link type %u, %u hop(s): not a direct xGMI link, so the "
-               "all-pairs schedule will run below its design rate on this pair", c->rank, c->device, peerRank, peerDev, type, hops);
+  const int direct = raTopoLinkIsDirect(type, hops);
+  if (direct) RA_INFO("rank %d (device %d) -> rank %d (device %d): xGMI, 1 hop", c->rank, c->device, peerRank, peerDev);
+  else RA_WARN("rank %d (device %d) -> rank %d (device %d): link type %u, %u hop(s): not a direct xGMI link",
+               c->rank, c->device, peerRank, peerDev, type, hops);
+  return direct;
 }
 
 ncclResult_t enablePeer(int myDev, int peerDev) {
@@ -308,6 +362,17 @@ void freeLocal(ncclComm* c) {
 }
 
 }  // namespace
+
+void raWindowLayoutFor(int nRanks, int* channels, RaWindowLayout* lay) {
+  ncclComm c;
+  c.nRanks = nRanks;
+  c.maxChannels = *channels;
+  c.multiProcess = true;
+  exchangeLimits(&c);
+  makeLayout(&c);
+  *channels = c.maxChannels;
+  *lay = c.lay;
+}
 
 RaClique::~RaClique() {
   DeviceGuard g;
@@ -421,6 +486,21 @@ ncclResult_t raCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
       c->peerWin[j] = cs[(size_t)j]->window;
       res = enablePeer(c->device, cs[(size_t)j]->device);
     }
+    // the same link matrix on every rank (both directions of a pair must be direct)
+    for (int a = 0; a < ndev; a++)
+      for (int b = 0; b < ndev; b++) {
+        if (a == b) { c->linkAdj[a * RA_MAX_RANKS + b] = 0; continue; }
+        uint32_t t1 = 0, h1 = 0, t2 = 0, h2 = 0;
+        const int da = devs[(size_t)a], db = devs[(size_t)b];
+        int direct = 1;
+        if (da != db) {
+          if (hipExtGetLinkTypeAndHopCount(da, db, &t1, &h1) == hipSuccess && hipExtGetLinkTypeAndHopCount(db, da, &t2, &h2) == hipSuccess)
+            direct = raTopoLinkIsDirect(t1, h1) && raTopoLinkIsDirect(t2, h2);
+          else (void)hipGetLastError();
+        }
+        c->linkAdj[a * RA_MAX_RANKS + b] = direct;
+      }
+    chooseDefaultSchedule(c);
     if (res == ncclSuccess) res = buildDevComm(c);
   }
   if (res != ncclSuccess) {
@@ -439,6 +519,7 @@ struct PeerInfo {            // one per rank, all-gathered at init (cf. src/incl
   uint64_t osBytes;
   uint64_t hostHash;
   uint64_t busId;            // hash of the device's PCI bus id: equal on two ranks = they share a GPU
+  char pciBusId[24];         // the id itself: a peer finds its own ordinal for that GPU with it
   uint64_t windowPtr;        // meaningful inside the owner's process only
   hipIpcMemHandle_t handle;
   int32_t haveHandle, pad;
@@ -496,6 +577,7 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
     memset(&me, 0, sizeof me);
     me.rank = rank; me.pid = (int32_t)getpid(); me.device = c->device; me.maxChannels = c->maxChannels;
     me.slotBytes = c->lay.slotBytes; me.nSlots = c->lay.nSlots; me.osBytes = c->lay.osBytes; me.hostHash = hostHash(); me.busId = busIdOf(c->device);
+    if (hipDeviceGetPCIBusId(me.pciBusId, (int)sizeof me.pciBusId, c->device) != hipSuccess) { (void)hipGetLastError(); me.pciBusId[0] = 0; }
     me.windowPtr = (uint64_t)(uintptr_t)c->window;
     me.haveHandle = hipIpcGetMemHandle(&me.handle, c->window) == hipSuccess;
     (void)hipGetLastError();
@@ -518,6 +600,8 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
       c->clique->joined++;
       windowOwned = true;
     }
+    int8_t myRow[RA_MAX_RANKS];
+    for (int p = 0; p < RA_MAX_RANKS; p++) myRow[p] = 1;
     for (int p = 0; p < nranks && res == ncclSuccess; p++) {
       const PeerInfo& pi = all[(size_t)p];
       if (pi.hostHash != me.hostHash) { RA_WARN("rank %d is on another host: only one node is supported", p); res = ncclInvalidUsage; break; }
@@ -528,7 +612,13 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
       }
       if (p == rank) { c->peerWin[p] = c->window; continue; }
       if (pi.pid != me.pid) c->peersElsewhere = true;
-      if (pi.busId != me.busId) describeLink(c, p, pi.device);
+      if (pi.busId != me.busId) {
+        // the peer's device number is its own process's; this process's number for the same GPU comes from the bus id
+        int local = -1;
+        if (pi.pid == me.pid) local = pi.device;
+        else if (!pi.pciBusId[0] || hipDeviceGetByPCIBusId(&local, pi.pciBusId) != hipSuccess) { (void)hipGetLastError(); local = -1; }
+        myRow[p] = (int8_t)describeLink(c, p, local);
+      }
       if (pi.pid == me.pid) {
         c->peerWin[p] = (char*)(uintptr_t)pi.windowPtr;
         res = enablePeer(c->device, pi.device);
@@ -547,6 +637,16 @@ ncclResult_t initRankBody(ncclComm* c, const ncclUniqueId& id) {
       for (int p = 0; p < nranks; p++)
         for (int q = 0; q < p; q++) shared = shared || all[(size_t)p].busId == all[(size_t)q].busId;
       setLLGrid(c, shared);
+    }
+    {
+      // every rank's view of its links, so that all of them build the same rings: a pair counts as linked when both
+      // ends say so
+      std::vector<int8_t> rows((size_t)nranks * RA_MAX_RANKS);
+      if ((res = c->boot.allGather(myRow, rows.data(), sizeof myRow)) != ncclSuccess) break;
+      for (int i = 0; i < nranks; i++)
+        for (int j = 0; j < nranks; j++)
+          c->linkAdj[i * RA_MAX_RANKS + j] = i != j && rows[(size_t)i * RA_MAX_RANKS + j] && rows[(size_t)j * RA_MAX_RANKS + i];
+      chooseDefaultSchedule(c);
     }
     if ((res = raRegInit(c, key)) != ncclSuccess) break;
     if ((res = buildDevComm(c)) != ncclSuccess) break;

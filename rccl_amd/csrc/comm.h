@@ -47,6 +47,7 @@ struct RaUserOp {
 };
 
 struct ncclComm {
+  ncclComm() { for (int i = 0; i < RA_MAX_RANKS * RA_MAX_RANKS; i++) linkAdj[i] = (i / RA_MAX_RANKS) != (i % RA_MAX_RANKS); }
   uint64_t magic = RA_COMM_MAGIC;
   int rank = 0, nRanks = 1, device = 0;
   bool blocking = true;
@@ -79,6 +80,8 @@ struct ncclComm {
   RaRegState* reg = nullptr;         // registration cache and boards (reg.cc)
   int nRings = 0;
   int8_t ringRanks[RA_MAX_CHANNELS][RA_MAX_RANKS];
+  int linkAdj[RA_MAX_RANKS * RA_MAX_RANKS];   // [a * RA_MAX_RANKS + b] = 1: ranks a and b are joined by one xGMI hop (or share a GPU)
+  bool allDirect = true;                      // every pair is: the all-pairs schedule is the default
 
   std::shared_ptr<RaClique> clique;
   RaBootstrap boot;
@@ -109,6 +112,9 @@ ncclResult_t raCommDestroy(ncclComm_t comm, bool abort);
 ncclResult_t raCommCheck(const ncclComm* comm, const char* what);
 ncclResult_t raCommPollError(ncclComm* comm);
 ncclResult_t raCommEnsureReady(const ncclComm* comm, const char* what);   // raCommCheck + the creation has ended well
+
+// The window layout a communicator of nRanks ranks gets for *channels channels (updated when the fit reduces them).
+void raWindowLayoutFor(int nRanks, int* channels, RaWindowLayout* lay);
 
 // enqueue.cc
 struct RaPlan {

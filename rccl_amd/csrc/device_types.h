@@ -62,9 +62,14 @@ __host__ __device__ inline size_t raFlagOffset(const RaWindowLayout& l, int whic
 __host__ __device__ inline size_t raFlagBytes(const RaWindowLayout& l) {
   return (size_t)(2 + l.nSlots) * l.nChannels * l.nRanks * RA_NKINDS * RA_FLAG_STRIDE;
 }
-// Slot storage of the FIFO on which `peer` sends to the window's owner.
-__host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, int peer, int kind) {
-  return l.dataOffset + ((((size_t)ch * l.nRanks + peer) * RA_NKINDS + kind) * l.nSlots) * (size_t)l.slotBytes;
+// Slot storage of the FIFO on which `sender` sends to the window's `owner`.  A window holds no FIFO from its owner to
+// itself: nRanks - 1 senders per channel, the owner skipped (an eighth of the FIFO storage at 8 ranks, half at 2).
+__host__ __device__ inline size_t raDataOffset(const RaWindowLayout& l, int ch, int owner, int sender, int kind) {
+  const int ix = sender < owner ? sender : sender - 1;
+  return l.dataOffset + ((((size_t)ch * (l.nRanks - 1) + ix) * RA_NKINDS + kind) * l.nSlots) * (size_t)l.slotBytes;
+}
+__host__ __device__ inline size_t raDataBytes(const RaWindowLayout& l) {
+  return (size_t)l.nChannels * (l.nRanks > 1 ? l.nRanks - 1 : 1) * RA_NKINDS * l.nSlots * (size_t)l.slotBytes;
 }
 
 // Low-latency protocol (reference: src/device/prims_ll.h:137-260): 16-byte lines
@@ -89,6 +94,7 @@ __host__ __device__ inline size_t raOsDataOffset(const RaWindowLayout& l, int bu
 // buffers in a static array every GPU holds, instead of a communicator's window.
 #define RA_NA_MAX_BYTES (256u << 10)   // largest payload per rank
 #define RA_NA_MAX_RANKS 8
+#define RA_NA_MAX_RANKS_PER_DEVICE 4     // ranks of one process whose kernels can run at the same time on one device
 #define RA_NA_GRID 16
 #define RA_NA_SENDER_BYTES ((size_t)RA_NA_MAX_BYTES * 2)                    // a 16-byte line per 8 payload bytes
 #define RA_NA_SCRATCH_BYTES (2 * RA_NA_MAX_RANKS * RA_NA_SENDER_BYTES)      // two alternating buffers: 8 MiB per GPU
@@ -101,7 +107,12 @@ struct RaNaArgs {
   uint64_t timeoutTicks;
   uint32_t epoch;                 // the same number on every rank of one call, larger than any earlier call's
   int rank, nRanks;
+  uint32_t* words;                // this GPU's status words (RA_NA_WORD_*): how a kernel reports that it gave up, and how the
+                                  // host tells kernels already launched to leave when a later launch of the call failed
 };
+enum { RA_NA_WORD_FAILED = 0,     // call number of the first call one of whose kernels gave up on this GPU (0: none)
+       RA_NA_WORD_CANCEL = 1,     // call number whose kernels must stop waiting at once
+       RA_NA_WORDS = 8 };
 // Broadcast and reduce put one presence line per workgroup in the tail of a sender's line buffer; their payloads stay at
 // or below RA_LL_DEFAULT_BYTES, so data lines never reach it.
 #define RA_LL_TOKEN_LINE ((size_t)RA_LL_MAX_BYTES / 8 - RA_LL_MAX_GRID)

@@ -63,77 +63,86 @@ hipError_t raLaunchLocal(void* dst, const void* const* srcs, int nsrc, int preId
 // runs on from the moment the module is loaded until the process ends, zero-filled at first (no line carries a
 // valid epoch).  `scratch` names the array for the compiler only; its address on a device comes from
 // hipGetSymbolAddress with that device current, once, and only that address is ever handed to a kernel.
+// `naWords` (the GPU's status words, RA_NA_WORD_*) is handled the same way.
 static __device__ __align__(256) unsigned char scratch[RA_NA_SCRATCH_BYTES];
+static __device__ __align__(256) uint32_t naWords[RA_NA_WORDS];
 
 #include <atomic>
 #include <mutex>
 
 static std::mutex gNaMutex;
 static char* gNaLines[64];             // per device: address of its `scratch`, null until set up
-static bool gNaPeer[64][64];           // [a][b]: kernels on device a may store into device b's memory
+static uint32_t* gNaWords[64];         // per device: address of its `naWords`
 static std::atomic<uint32_t> gNaEpoch{0};
 
-// The address of `dev`'s array (set-up on the first call for a device; the current device is left as found).
-static hipError_t naLines(int dev, char** out) {
+// The addresses of `dev`'s arrays (set-up on the first call for a device; the current device is left as found).
+static hipError_t naSetup(int dev, char** lines, uint32_t** words) {
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   std::lock_guard<std::mutex> g(gNaMutex);
-  if (!gNaLines[dev]) {
+  if (!gNaLines[dev] || !gNaWords[dev]) {
     int cur = 0;
     hipError_t e = hipGetDevice(&cur);
     if (e != hipSuccess) return e;
     if ((e = hipSetDevice(dev)) != hipSuccess) return e;
     void* p = nullptr;
+    void* q = nullptr;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e == hipSuccess) e = hipGetSymbolAddress(&q, HIP_SYMBOL(naWords));
     hipError_t back = hipSetDevice(cur);
     if (e != hipSuccess) return e;
     if (back != hipSuccess) return back;
-    if (!p) return hipErrorInvalidSymbol;
+    if (!p || !q) return hipErrorInvalidSymbol;
     gNaLines[dev] = (char*)p;
+    gNaWords[dev] = (uint32_t*)q;
   }
-  *out = gNaLines[dev];
+  *lines = gNaLines[dev];
+  *words = gNaWords[dev];
   return hipSuccess;
 }
 
-hipError_t raNoAllocAllReduce(const void* const* send, void* const* recv, const int* devices, int nRanks, size_t count,
+// All ranks on ONE device (the caller has checked that).  A launch that fails after earlier ranks' kernels are already
+// waiting cancels the call: the call's number goes into the GPU's cancel word, which every waiting kernel polls.
+hipError_t raNoAllocAllReduce(const void* const* send, void* const* recv, int device, int nRanks, size_t count,
                               int dtype, int op, uint64_t opArg, uint64_t timeoutTicks, const hipStream_t* streams) {
   if (nRanks < 1 || nRanks > RA_NA_MAX_RANKS) return hipErrorInvalidValue;
   RaNaArgs a;
-  for (int p = 0; p < RA_NA_MAX_RANKS; p++) a.lines[p] = nullptr;
-  for (int p = 0; p < nRanks; p++) {
-    hipError_t e = naLines(devices[p], &a.lines[p]);
-    if (e != hipSuccess) return e;
-  }
-  int cur = 0;
-  hipError_t e = hipGetDevice(&cur);
+  char* lines = nullptr;
+  hipError_t e = naSetup(device, &lines, &a.words);
   if (e != hipSuccess) return e;
-  {
-    // once per ordered pair of distinct devices: the peer mapping the line stores need
-    std::lock_guard<std::mutex> g(gNaMutex);
-    for (int x = 0; x < nRanks; x++) {
-      for (int y = 0; y < nRanks; y++) {
-        const int dx = devices[x], dy = devices[y];
-        if (dx == dy || gNaPeer[dx][dy]) continue;
-        if ((e = hipSetDevice(dx)) != hipSuccess) return e;
-        e = hipDeviceEnablePeerAccess(dy, 0);
-        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
-        if (e != hipSuccess) { (void)hipSetDevice(cur); return e; }
-        gNaPeer[dx][dy] = true;
-      }
-    }
-  }
+  for (int p = 0; p < RA_NA_MAX_RANKS; p++) a.lines[p] = p < nRanks ? lines : nullptr;
+  int cur = 0;
+  if ((e = hipGetDevice(&cur)) != hipSuccess) return e;
+  if (cur != device && (e = hipSetDevice(device)) != hipSuccess) return e;
   uint32_t epoch = gNaEpoch.fetch_add(1) + 1;
   if (epoch == 0) epoch = gNaEpoch.fetch_add(1) + 1;
   a.count = count; a.opArg = opArg; a.timeoutTicks = timeoutTicks; a.epoch = epoch; a.nRanks = nRanks;
+  int launched = 0;
   for (int r = 0; r < nRanks && e == hipSuccess; r++) {
     a.rank = r; a.send = send[r]; a.recv = recv[r];
-    if ((e = hipSetDevice(devices[r])) != hipSuccess) break;
     switch (dtype) {
 #define RA_CASE(N) case N: e = raLaunchNoAllocDt##N(a, op, streams[r]); break;
       RA_CASE(0) RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8) RA_CASE(9) RA_CASE(10) RA_CASE(11)
 #undef RA_CASE
       default: e = hipErrorInvalidValue;
     }
+    if (e == hipSuccess) launched++;
   }
-  hipError_t back = hipSetDevice(cur);
+  if (e != hipSuccess && launched > 0)      // the kernels already launched would wait for lines that never come
+    (void)hipMemcpy(a.words + RA_NA_WORD_CANCEL, &epoch, sizeof epoch, hipMemcpyHostToDevice);
+  hipError_t back = cur != device ? hipSetDevice(cur) : hipSuccess;
+  return e != hipSuccess ? e : back;
+}
+
+// The call number of the first call that gave up on `device` (0: none).  A 4-byte copy from the device: no allocation.
+hipError_t raNoAllocFailedCall(int device, uint32_t* call) {
+  char* lines = nullptr;
+  uint32_t* words = nullptr;
+  hipError_t e = naSetup(device, &lines, &words);
+  if (e != hipSuccess) return e;
+  int cur = 0;
+  if ((e = hipGetDevice(&cur)) != hipSuccess) return e;
+  if (cur != device && (e = hipSetDevice(device)) != hipSuccess) return e;
+  e = hipMemcpy(call, words + RA_NA_WORD_FAILED, sizeof *call, hipMemcpyDeviceToHost);
+  hipError_t back = cur != device ? hipSetDevice(cur) : hipSuccess;
   return e != hipSuccess ? e : back;
 }

@@ -724,12 +724,12 @@ struct Ctx {
   }
   // Slot I fill next on the FIFO towards `peer` (it lives in peer's window).
   __device__ __forceinline__ char* sendSlot(int peer, int kind) const {
-    return comm->win[peer] + raDataOffset(comm->lay, ch, rank, kind) +
+    return comm->win[peer] + raDataOffset(comm->lay, ch, peer, rank, kind) +
            (sh->sendStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
   }
   // Slot I drain next on the FIFO from `peer` (it lives in my window).
   __device__ __forceinline__ const char* recvSlot(int peer, int kind) const {
-    return comm->win[rank] + raDataOffset(comm->lay, ch, peer, kind) +
+    return comm->win[rank] + raDataOffset(comm->lay, ch, rank, peer, kind) +
            (sh->recvStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
   }
 
@@ -1788,7 +1788,9 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLRingKernel(const RaDevComm*
 // Same protocol as raLLAllReduceKernel, all state in the kernel arguments: a.lines[p] is rank p's line array, the
 // lines of sender q for buffer b start at (b * RA_NA_MAX_RANKS + q) * RA_NA_SENDER_BYTES.  Ranks that share a GPU
 // share one array; what sender q stores is the same for every receiver, so they may share q's region too.
-// A wait that outlasts a.timeoutTicks gives up and leaves that thread's outputs unwritten.
+// A wait that outlasts a.timeoutTicks, or that sees the call cancelled (a later launch of the same call failed on the
+// host), gives up: the thread's outputs stay unwritten and the call's number goes into the GPU's status word, where
+// rcclAmdNoAllocAsyncError finds it.
 template <typename T, int OP>
 __global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaArgs a) {
   const int n = a.nRanks, r = a.rank;
@@ -1824,7 +1826,16 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaAr
           do {
             __builtin_amdgcn_s_sleep(1);
             line = llLoadLine(lp);
-            if ((++spins & 0xff) == 0 && wall_clock64() - t0 > a.timeoutTicks) { dead = true; break; }
+            if ((++spins & 0xff) == 0) {
+              const bool cancelled = __hip_atomic_load(a.words + RA_NA_WORD_CANCEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == epoch;
+              if (cancelled || wall_clock64() - t0 > a.timeoutTicks) {
+                uint32_t expect = 0;
+                __hip_atomic_compare_exchange_strong(a.words + RA_NA_WORD_FAILED, &expect, epoch, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
+                break;
+              }
+            }
           } while (line.y != epoch || line.w != epoch);
         }
         x = (uint64_t)line.x | ((uint64_t)line.z << 32);

@@ -20,10 +20,12 @@ hipError_t raLaunchLL(const RaDevComm* comm, const RaWork& w, int dtype, int op,
 hipError_t raLaunchLocal(void* dst, const void* const* srcs, int nsrc, int preIdx, bool post, uint64_t opArg,
                          const void* opArgPtr, size_t nelem, int dtype, int op, int grid, hipStream_t s);
 
-// All-reduce over nRanks buffers, rank r on devices[r] and streams[r], that allocates nothing: its line buffers are a
-// static array on every GPU (payload per rank at most RA_NA_MAX_BYTES, at most RA_NA_MAX_RANKS ranks).
-hipError_t raNoAllocAllReduce(const void* const* send, void* const* recv, const int* devices, int nRanks, size_t count,
+// All-reduce over nRanks buffers on ONE device, rank r on streams[r], that allocates nothing: its line buffers are a
+// static array the GPU holds (payload per rank at most RA_NA_MAX_BYTES, at most RA_NA_MAX_RANKS ranks).
+hipError_t raNoAllocAllReduce(const void* const* send, void* const* recv, int device, int nRanks, size_t count,
                               int dtype, int op, uint64_t opArg, uint64_t timeoutTicks, const hipStream_t* streams);
+// Number of the first such call one of whose kernels gave up waiting on `device` (0: none).
+hipError_t raNoAllocFailedCall(int device, uint32_t* call);
 
 // Grid for a local kernel producing `outBytes` from `nsrc` sources: one tile per workgroup (a tile is
 // RA_LOCAL_THREADS x U packs with nsrc*U = 8, see reduceCopy), grid-stride beyond 64 Ki tiles.

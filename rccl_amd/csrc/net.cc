@@ -103,7 +103,7 @@ struct RaNet {
               uint64_t nbytes = __atomic_load_n(flagAt(sh, lay, 2 + slot, ch, rank, k), __ATOMIC_RELAXED);
               if (nbytes > lay.slotBytes) nbytes = lay.slotBytes;
               MsgHeader h{MSG_DATA, (uint32_t)ch, (uint32_t)k, (uint32_t)nbytes, step};
-              const char* data = sh + raDataOffset(lay, ch, rank, k) + (size_t)slot * lay.slotBytes;
+              const char* data = sh + raDataOffset(lay, ch, p, rank, k) + (size_t)slot * lay.slotBytes;
               if (!sendAll(sock[(size_t)p], &h, sizeof h) || !sendAll(sock[(size_t)p], data, (size_t)nbytes)) { fail("send"); return; }
               bytesSent += nbytes;
               st = step;
@@ -149,7 +149,7 @@ struct RaNet {
         if ((int)h.ch >= lay.nChannels || h.kind >= RA_NKINDS || h.nbytes > lay.slotBytes) { errno = EPROTO; fail("message check"); return; }
         if (h.type == MSG_DATA) {
           const int slot = (int)((h.step - 1) % (uint64_t)lay.nSlots);
-          char* dst = real + raDataOffset(lay, (int)h.ch, p, (int)h.kind) + (size_t)slot * lay.slotBytes;
+          char* dst = real + raDataOffset(lay, (int)h.ch, rank, p, (int)h.kind) + (size_t)slot * lay.slotBytes;
           if (h.nbytes && !recvAll(pf[i].fd, dst, h.nbytes)) { if (!stop.load()) fail("recv"); return; }
           __atomic_store_n(flagAt(real, lay, 0, (int)h.ch, p, (int)h.kind), h.step, __ATOMIC_RELEASE);
         } else if (h.type == MSG_CREDIT) {

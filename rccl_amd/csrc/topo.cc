@@ -108,6 +108,8 @@ bool greedyRing(int n, const int* adj, std::vector<int>& use, std::vector<int>& 
 
 }  // namespace
 
+int raTopoLinkIsDirect(unsigned type, unsigned hops) { return type == 4u && hops == 1u; }
+
 int raTopoRings(int n, const int* adj, int maxRings, std::vector<std::vector<int>>& rings) {
   rings.clear();
   if (n < 1 || n > 16 || maxRings < 1) return 0;
@@ -222,4 +224,21 @@ extern "C" __attribute__((visibility("default"))) ncclResult_t rcclAmdTopoRings(
 extern "C" __attribute__((visibility("default"))) ncclResult_t rcclAmdTopoParseXml(const char* xmlText, int maxGpus, int* adj, int* ngpus) {
   if (!xmlText || !adj || !ngpus || maxGpus < 1) return ncclInvalidArgument;
   return raTopoParseXml(xmlText, maxGpus, adj, ngpus) == 0 ? ncclSuccess : ncclInvalidArgument;
+}
+
+// Adjacency and default schedule from a link table (linkType / hops: n x n as hipExtGetLinkTypeAndHopCount reports them,
+// diagonal ignored): adj[a][b] = 1 when both directions of the pair are one xGMI hop; *allDirect = every pair is.
+extern "C" __attribute__((visibility("default"))) ncclResult_t rcclAmdTopoFromLinks(int ngpus, const unsigned* linkType, const unsigned* hops,
+                                                                                   int* adj, int* allDirect) {
+  if (ngpus < 1 || ngpus > 16 || !linkType || !hops || !adj) return ncclInvalidArgument;
+  int all = 1;
+  for (int a = 0; a < ngpus; a++)
+    for (int b = 0; b < ngpus; b++) {
+      const int d = a != b && raTopoLinkIsDirect(linkType[a * ngpus + b], hops[a * ngpus + b]) &&
+                    raTopoLinkIsDirect(linkType[b * ngpus + a], hops[b * ngpus + a]);
+      adj[a * ngpus + b] = d;
+      if (a != b && !d) all = 0;
+    }
+  if (allDirect) *allDirect = all;
+  return ncclSuccess;
 }

@@ -36,6 +36,7 @@ EXPORTS = [
     "ncclCommSplit", "ncclGather", "ncclScatter", "ncclAllToAll", "ncclAllToAllv", "mscclLoadAlgo", "mscclRunAlgo",
     "mscclUnloadAlgo", "rcclAmdReduceCopy", "rcclAmdTopoRings", "rcclAmdTopoParseXml", "rcclAmdPlanInfo",
     "rcclAmdPlanForConfig", "rcclAmdPlanProtoForConfig", "rcclAmdBootstrapAllGather", "rcclAmdAllReduceNoAlloc",
+    "rcclAmdNoAllocAsyncError", "rcclAmdTopoFromLinks", "rcclAmdWindowBytesFor",
 ]
 EXPORTS += ["p" + name for name in EXPORTS if name.startswith(("nccl", "msccl"))]      # profiling aliases
 
@@ -113,6 +114,9 @@ def lib():
                                            ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
         L.rcclAmdPlanProtoForConfig.argtypes = [ci, ci, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.rcclAmdBootstrapAllGather.argtypes = [ctypes.POINTER(ncclUniqueId), ci, ci, vp, vp, sz]
+        L.rcclAmdNoAllocAsyncError.argtypes = [ci, ctypes.POINTER(ci)]
+        L.rcclAmdTopoFromLinks.argtypes = [ci, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.rcclAmdWindowBytesFor.argtypes = [ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(ci)]
         _lib = L
     return _lib
 
@@ -344,6 +348,33 @@ def all_reduce_no_alloc(sendbuffs, recvbuffs, devices, count, datatype, op=ncclS
     dv = (ctypes.c_int * n)(*[int(d) for d in devices])
     st = (ctypes.c_void_p * n)(*[_stream(x).value for x in streams])
     _check(lib().rcclAmdAllReduceNoAlloc(sb, rb, dv, n, count, datatype, op, st), "rcclAmdAllReduceNoAlloc")
+
+
+def no_alloc_async_error(device=0):
+    """rcclAmdNoAllocAsyncError: ncclSuccess, or ncclRemoteError once a kernel of a no-alloc call gave up on `device`."""
+    err = ctypes.c_int()
+    _check(lib().rcclAmdNoAllocAsyncError(device, ctypes.byref(err)), "rcclAmdNoAllocAsyncError")
+    return err.value
+
+
+def topo_from_links(link_type, hops):
+    """rcclAmdTopoFromLinks: (adjacency matrix, all pairs direct?) from n x n link types and hop counts."""
+    n = len(link_type)
+    t = (ctypes.c_uint * (n * n))(*[int(x) for row in link_type for x in row])
+    h = (ctypes.c_uint * (n * n))(*[int(x) for row in hops for x in row])
+    adj = (ctypes.c_int * (n * n))()
+    allp = ctypes.c_int()
+    _check(lib().rcclAmdTopoFromLinks(n, t, h, adj, ctypes.byref(allp)), "rcclAmdTopoFromLinks")
+    return [[adj[i * n + j] for j in range(n)] for i in range(n)], bool(allp.value)
+
+
+def window_bytes_for(nranks, channels):
+    """rcclAmdWindowBytesFor: dict(total, fifo, exchange, channels) of the per-rank window."""
+    tot, fifo, exch = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    ch = ctypes.c_int()
+    _check(lib().rcclAmdWindowBytesFor(nranks, channels, ctypes.byref(tot), ctypes.byref(fifo), ctypes.byref(exch), ctypes.byref(ch)),
+           "rcclAmdWindowBytesFor")
+    return dict(total=tot.value, fifo=fifo.value, exchange=exch.value, channels=ch.value)
 
 
 def topo_rings(ngpus, adj, max_rings=64):

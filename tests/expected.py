@@ -18,10 +18,13 @@ ALGO_DIRECT, ALGO_RING, ALGO_TREE = 0, 1, 2
 
 
 def full_rings(n):
-    """Ring orders the library uses on n all-to-all ranks (CPU call into the library)."""
-    import rccl_amd as ra
-    adj = [[0 if i == j else 1 for j in range(n)] for i in range(n)]
-    rings = ra.topo_rings(n, adj)
+    """Ring orders on n all-to-all ranks, from the committed fixture (tests/golden/ring_orders_all_to_all.json), not from
+    the library: tests/test_topo.py holds the library's ring search to the same file, so an expectation in ring or chain
+    order never silently follows a change of that search."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ring_orders_all_to_all.json")) as f:
+        rings = json.load(f)[str(n)]
     return rings if rings else [list(range(n))]
 
 

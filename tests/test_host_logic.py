@@ -166,3 +166,47 @@ def test_rendezvous_world_size_n_gloo(world):
         p.join(timeout=30)
     for r in range(world):
         assert res[r] == [bytes([k + 1]) * 64 for k in range(world)], res[r]
+
+
+def test_window_stays_inside_its_budget():
+    """The per-rank window (the reference's per-connection buffers, src/transport/p2p.cc:447-450) is fitted into
+    1.5 GiB for every rank count and any channel count up to 64, well clear of the 2 GiB at which windows shared
+    between processes are refused; the default geometry at 8 ranks is not touched by the fit."""
+    MiB = 1 << 20
+    for n in range(2, 17):
+        for ch in (8, 16, 24, 32, 48, 56, 64):
+            w = ra.window_bytes_for(n, ch)
+            assert w["total"] <= 1536 * MiB, (n, ch, w)
+            assert w["channels"] == ch, (n, ch, w)           # the fit never had to give up channels in this range
+            assert w["fifo"] + w["exchange"] < w["total"]
+    w = ra.window_bytes_for(8, 56)
+    # 56 channels x 7 peers x 2 kinds x 2 slots x 768 KiB, two exchange buffers of 8 senders x 2 x (64 MiB / 8)
+    assert w["fifo"] == 56 * 7 * 2 * 2 * 768 * 1024 and 256 * MiB <= w["exchange"] < 258 * MiB, w
+    assert ra.window_bytes_for(8, 64)["exchange"] < 130 * MiB          # the exchange region gave way first
+    assert ra.window_bytes_for(2, 32)["fifo"] == 32 * 1 * 2 * 2 * 768 * 1024
+
+
+def test_rings_follow_the_links_that_exist():
+    """Adjacency from link types and hop counts (hipExtGetLinkTypeAndHopCount; the reference: src/graph/xml.cc:780-791):
+    every pair one xGMI hop -> all-pairs schedule stays the default; a pair that is not -> rings that avoid it."""
+    n = 8
+    xgmi = [[0 if i == j else 4 for j in range(n)] for i in range(n)]
+    one = [[0 if i == j else 1 for j in range(n)] for i in range(n)]
+    adj, all_direct = ra.topo_from_links(xgmi, one)
+    assert all_direct and all(adj[i][j] == (i != j) for i in range(n) for j in range(n))
+    # one direction of one pair goes over PCIe (type 2): the pair is out, both ways
+    pcie = [row[:] for row in xgmi]
+    pcie[2][5] = 2
+    adj, all_direct = ra.topo_from_links(pcie, one)
+    assert not all_direct and adj[2][5] == 0 and adj[5][2] == 0 and sum(map(sum, adj)) == n * (n - 1) - 2
+    rings = ra.topo_rings(n, adj)
+    assert rings
+    for r in rings:
+        assert sorted(r) == list(range(n))
+        for i in range(n):
+            assert adj[r[i]][r[(i + 1) % n]], (r, i)
+    # two hops over xGMI is not a direct link either
+    far = [row[:] for row in one]
+    far[0][7] = far[7][0] = 2
+    adj, all_direct = ra.topo_from_links(xgmi, far)
+    assert not all_direct and adj[0][7] == 0

@@ -96,3 +96,14 @@ def test_synthesis_on_a_plain_ring_topology():
 def test_synthesis_rejects_bad_arguments():
     with pytest.raises(ra.NcclError):
         ra.topo_rings(0, [])
+
+
+def test_ring_orders_match_the_committed_fixture():
+    """The ring orders the kernels walk on all-to-all nodes of 2..16 ranks are pinned: tests/expected.py builds its
+    ring- and chain-order expectations from this fixture, so the search cannot drift without a test saying so."""
+    import json
+    with open(os.path.join(GOLD, "ring_orders_all_to_all.json")) as f:
+        fixture = json.load(f)
+    for n in range(2, 17):
+        adj = [[0 if i == j else 1 for j in range(n)] for i in range(n)]
+        assert ra.topo_rings(n, adj) == fixture[str(n)], n
