@@ -2,13 +2,15 @@
 // per-type translation units built from kernels_dtype.hip.
 #include "kernels_impl.h"
 
+enum { RA_G_BROADCAST, RA_G_DIRECT_ALLGATHER, RA_G_RING_ALLGATHER };
+template <int K>
 __global__ __launch_bounds__(1024) void raGatherKernel(const RaDevComm* __restrict__ comm, RaWork w) {
-  __shared__ ChanShared sh;
+  __shared__ ChanShared shA;
   Ctx cx;
   const int role = blockIdx.x / w.nChannels;
-  cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
-  if (w.coll == RA_COLL_BROADCAST) directBroadcast(cx, w, role);
-  else if (w.algo == RA_ALGO_DIRECT) directAllGather(cx, w, role);
+  cx.init(comm, RA_LDS_CHAN(shA), blockIdx.x % w.nChannels, w.stepBytes);
+  if constexpr (K == RA_G_BROADCAST) directBroadcast(cx, w, role);
+  else if constexpr (K == RA_G_DIRECT_ALLGATHER) directAllGather(cx, w, role);
   else ringAllGather(cx, w);
   cx.finish();
 }
@@ -23,7 +25,9 @@ RA_DECL(0) RA_DECL(1) RA_DECL(2) RA_DECL(3) RA_DECL(4) RA_DECL(5) RA_DECL(6) RA_
 
 hipError_t raLaunchColl(const RaDevComm* comm, const RaWork& w, int dtype, int op, int grid, int block, hipStream_t s) {
   if ((w.coll == RA_COLL_ALLGATHER && !w.oneShot) || w.coll == RA_COLL_BROADCAST) {
-    hipLaunchKernelGGL(raGatherKernel, dim3(grid), dim3(block), 0, s, comm, w);
+    if (w.coll == RA_COLL_BROADCAST) hipLaunchKernelGGL(raGatherKernel<RA_G_BROADCAST>, dim3(grid), dim3(block), 0, s, comm, w);
+    else if (w.algo == RA_ALGO_DIRECT) hipLaunchKernelGGL(raGatherKernel<RA_G_DIRECT_ALLGATHER>, dim3(grid), dim3(block), 0, s, comm, w);
+    else hipLaunchKernelGGL(raGatherKernel<RA_G_RING_ALLGATHER>, dim3(grid), dim3(block), 0, s, comm, w);
     return hipGetLastError();
   }
   switch (dtype) {

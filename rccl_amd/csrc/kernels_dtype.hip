@@ -39,8 +39,21 @@ typedef f8e5m2_t elem_t;
 
 template <int OP>
 static hipError_t collOp(const RaDevComm* comm, const RaWork& w, int grid, int block, hipStream_t s) {
-  if (w.oneShot) hipLaunchKernelGGL((raOneShotKernel<elem_t, OP>), dim3(grid), dim3(1024), 0, s, comm, w);
-  else hipLaunchKernelGGL((raCollKernel<elem_t, OP>), dim3(grid), dim3(block), 0, s, comm, w);
+  if (w.oneShot == 2) hipLaunchKernelGGL((raTwoExchangeKernel<elem_t, OP>), dim3(grid), dim3(1024), 0, s, comm, w);
+  else if (w.oneShot) hipLaunchKernelGGL((raOneShotKernel<elem_t, OP>), dim3(grid), dim3(1024), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_DIRECT && w.coll == RA_COLL_ALLREDUCE)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_DIRECT_ALLREDUCE>), dim3(grid), dim3(block), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_DIRECT && w.coll == RA_COLL_REDUCESCATTER)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_DIRECT_REDUCESCATTER>), dim3(grid), dim3(block), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_DIRECT && w.coll == RA_COLL_REDUCE)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_DIRECT_REDUCE>), dim3(grid), dim3(block), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_RING && w.coll == RA_COLL_ALLREDUCE)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_RING_ALLREDUCE>), dim3(grid), dim3(block), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_RING && w.coll == RA_COLL_REDUCESCATTER)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_RING_REDUCESCATTER>), dim3(grid), dim3(block), 0, s, comm, w);
+  else if (w.algo == RA_ALGO_TREE && w.coll == RA_COLL_ALLREDUCE)
+    hipLaunchKernelGGL((raCollKernel<elem_t, OP, RA_K_CHAIN_ALLREDUCE>), dim3(grid), dim3(block), 0, s, comm, w);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 template <int OP>

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.h"
+#include "f8_math.h"
 #include "launch.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -35,37 +36,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 
 // 8-bit floats in the reference's encoding (rccl_float8 = E4M3, rccl_bfloat8 = E5M2; 0x80 is NaN, no
 // negative zero, no infinity, bias 2^(we-1); src/include/rccl_float8.h:61-329).  Conversion from float
-// rounds to nearest even and clips to the largest finite value (rccl_float8.h:48).
+// rounds to nearest even and clips to the largest finite value (rccl_float8.h:48).  The arithmetic lives in f8_math.h
+// (branch-free, checked on the host for all 256 codes and all 2^32 floats).
 template <int WM> struct f8_t { uint8_t v; };
 typedef f8_t<3> f8e4m3_t;
 typedef f8_t<2> f8e5m2_t;
-// Both directions are branch-free (a dozen and about twenty integer / float instructions): checked against the
-// reference's conversions for all 256 codes and all 2^32 floats.
-template <int WM> __device__ __forceinline__ float f8ToF(f8_t<WM> a) {
-  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1);
-  const uint32_t x = a.v, mag = x & 0x7fu;
-  const float fn = __uint_as_float((mag << (23 - WM)) + ((uint32_t)(127 - BIAS) << 23));            // normal codes
-  const float fs = (float)mag * __uint_as_float((uint32_t)(127 + 1 - BIAS - WM) << 23);             // exponent field 0
-  const float f = __uint_as_float(__float_as_uint((mag >> WM) ? fn : fs) | ((x & 0x80u) << 24));
-  return x == 0x80u ? __uint_as_float(0x7f800001u) : f;
-}
-template <int WM> __device__ __forceinline__ f8_t<WM> fToF8(float v) {
-  constexpr int WE = 7 - WM, BIAS = 1 << (WE - 1);
-  const uint32_t u = __float_as_uint(v), sign = (u >> 24) & 0x80u, a = u & 0x7fffffffu;
-  constexpr uint32_t minNormal = (uint32_t)(127 + 1 - BIAS) << 23;
-  // normal range: round to nearest even on the 23-WM dropped bits (a carry moves into the exponent), then rebias
-  const uint32_t r = a + ((a >> (23 - WM)) & 1u) + ((1u << (22 - WM)) - 1u);
-  const uint32_t cn = (r >> (23 - WM)) - ((uint32_t)(127 - BIAS) << WM);
-  // below the smallest normal: adding 2^(1-BIAS-WM+23) makes the adder round to the fixed quantum 2^(1-BIAS-WM)
-  constexpr uint32_t magic = (uint32_t)(127 + 1 - BIAS - WM + 23) << 23;
-  const uint32_t cs = __float_as_uint(__uint_as_float(a) + __uint_as_float(magic)) - magic;
-  uint32_t c = a >= minNormal ? cn : cs;
-  c = c > 0x7fu ? 0x7fu : c;                             // clipped to the largest finite value
-  f8_t<WM> out;
-  out.v = (uint8_t)(a >= 0x7f800000u ? 0x80u : (c ? (sign | c) : 0u));   // infinity / NaN -> 0x80; no negative zero
-  return out;
-}
+template <int WM> __device__ __forceinline__ float f8ToF(f8_t<WM> a) { return f8Decode<WM>(a.v); }
+template <int WM> __device__ __forceinline__ f8_t<WM> fToF8(float v) { f8_t<WM> out; out.v = (uint8_t)f8Encode<WM>(v); return out; }
 
+template <typename T> struct IsF8 { static constexpr bool value = false; };
+template <int WM> struct IsF8<f8_t<WM>> { static constexpr bool value = true; };
 template <typename T> struct IsInt { static constexpr bool value = true; };
 template <> struct IsInt<float> { static constexpr bool value = false; };
 template <> struct IsInt<double> { static constexpr bool value = false; };
@@ -173,46 +153,140 @@ template <typename T, int OP> struct PackOps {
     return x.v;
   }
 };
-// The 8-bit floats convert in software (two decodes, the operation and an encode: about 45 instructions per element),
-// so their pack ops stay out of line, four elements per call: the copy loops around them keep their shape and the
-// code stays small.
-template <int WM, int R> __device__ __noinline__ uint32_t f8Red4(uint32_t a, uint32_t b) {
+// 8-bit integers, four to a dword, without taking the dword apart (the reference's SWAR byte sum:
+// src/device/reduce_kernel.h:183-193): sums carry-free through a 7-bit add plus the top bits' exclusive or; products,
+// maxima and minima on the even and the odd bytes as two lanes of 16 bits each (v_pk_mul_lo_u16, v_pk_max / v_pk_min;
+// signed bytes ride in the high byte of their lane, where a 16-bit signed compare orders them).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t asU32(u16x2 v) { union { u16x2 p; uint32_t u; } x; x.p = v; return x.u; }
+__device__ __forceinline__ uint32_t asU32(i16x2 v) { union { i16x2 p; uint32_t u; } x; x.p = v; return x.u; }
+__device__ __forceinline__ u16x2 asU16x2(uint32_t u) { union { u16x2 p; uint32_t u; } x; x.u = u; return x.p; }
+__device__ __forceinline__ i16x2 asI16x2(uint32_t u) { union { i16x2 p; uint32_t u; } x; x.u = u; return x.p; }
+template <bool SIGNED, int R> __device__ __forceinline__ uint32_t byteRed4(uint32_t a, uint32_t b) {
+  if (R == RA_OP_SUM) return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u);
+  if (R == RA_OP_PROD) {
+    const u16x2 e = asU16x2(a & 0x00ff00ffu) * asU16x2(b & 0x00ff00ffu);
+    const u16x2 o = asU16x2((a >> 8) & 0x00ff00ffu) * asU16x2((b >> 8) & 0x00ff00ffu);
+    return (asU32(e) & 0x00ff00ffu) | ((asU32(o) & 0x00ff00ffu) << 8);
+  }
+  if (SIGNED) {
+    const i16x2 ae = asI16x2((a << 8) & 0xff00ff00u), be = asI16x2((b << 8) & 0xff00ff00u);
+    const i16x2 ao = asI16x2(a & 0xff00ff00u), bo = asI16x2(b & 0xff00ff00u);
+    const i16x2 e = R == RA_OP_MAX ? __builtin_elementwise_max(ae, be) : __builtin_elementwise_min(ae, be);
+    const i16x2 o = R == RA_OP_MAX ? __builtin_elementwise_max(ao, bo) : __builtin_elementwise_min(ao, bo);
+    return ((asU32(e) >> 8) & 0x00ff00ffu) | (asU32(o) & 0xff00ff00u);
+  }
+  const u16x2 ae = asU16x2(a & 0x00ff00ffu), be = asU16x2(b & 0x00ff00ffu);
+  const u16x2 ao = asU16x2((a >> 8) & 0x00ff00ffu), bo = asU16x2((b >> 8) & 0x00ff00ffu);
+  const u16x2 e = R == RA_OP_MAX ? __builtin_elementwise_max(ae, be) : __builtin_elementwise_min(ae, be);
+  const u16x2 o = R == RA_OP_MAX ? __builtin_elementwise_max(ao, bo) : __builtin_elementwise_min(ao, bo);
+  return asU32(e) | (asU32(o) << 8);
+}
+// every byte times the byte `s` (FuncPreMulSum on 8-bit integers: the product's low byte)
+__device__ __forceinline__ uint32_t byteMul4(uint32_t a, uint32_t s) {
+  const u16x2 k = {(uint16_t)s, (uint16_t)s};
+  const u16x2 e = asU16x2(a & 0x00ff00ffu) * k, o = asU16x2((a >> 8) & 0x00ff00ffu) * k;
+  return (asU32(e) & 0x00ff00ffu) | ((asU32(o) & 0x00ff00ffu) << 8);
+}
+// every byte divided by n, truncating as C does (FuncSumPostDiv, src/device/reduce_kernel.h:546-573).  |x| * ceil(2^16 / n)
+// >> 16 is floor(|x| / n) for |x| <= 255 and n <= 256 (the error term |x| * (n ceil(2^16/n) - 2^16) stays below 2^16).
+template <bool SIGNED> __device__ __forceinline__ uint32_t byteDiv4(uint32_t a, uint32_t n) {
+  const uint32_t m = (65536u + n - 1u) / n;
   uint32_t r = 0;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    f8_t<WM> x, y; x.v = (uint8_t)(a >> (8 * i)); y.v = (uint8_t)(b >> (8 * i));
-    r |= (uint32_t)Elem<f8_t<WM>, R>::red(x, y).v << (8 * i);
+    if (SIGNED) {
+      const int x = (int)(int8_t)(a >> (8 * i));
+      const uint32_t q = (__umul24((uint32_t)(x < 0 ? -x : x), m)) >> 16;
+      r |= ((uint32_t)(x < 0 ? -(int)q : (int)q) & 0xffu) << (8 * i);
+    } else {
+      r |= ((__umul24((a >> (8 * i)) & 0xffu, m) >> 16) & 0xffu) << (8 * i);
+    }
   }
   return r;
 }
-template <int WM> __device__ __noinline__ uint32_t f8Pre4(uint32_t a, uint32_t arg) {
-  uint32_t r = 0;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    f8_t<WM> x; x.v = (uint8_t)(a >> (8 * i));
-    r |= (uint32_t)Scale<f8_t<WM>>::pre(x, arg).v << (8 * i);
-  }
-  return r;
-}
-template <int WM, int OP> struct PackOps<f8_t<WM>, OP> {
+template <bool SIGNED, int OP> struct BytePackOps {
+  static constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
   static __device__ __forceinline__ u32x4 red(u32x4 a, u32x4 b) {
-    constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
     u32x4 r;
-    r.x = f8Red4<WM, R>(a.x, b.x); r.y = f8Red4<WM, R>(a.y, b.y);
-    r.z = f8Red4<WM, R>(a.z, b.z); r.w = f8Red4<WM, R>(a.w, b.w);
+    r.x = byteRed4<SIGNED, R>(a.x, b.x); r.y = byteRed4<SIGNED, R>(a.y, b.y);
+    r.z = byteRed4<SIGNED, R>(a.z, b.z); r.w = byteRed4<SIGNED, R>(a.w, b.w);
     return r;
   }
   static __device__ __forceinline__ u32x4 pre(u32x4 a, uint64_t arg) {
-    u32x4 r;
-    r.x = f8Pre4<WM>(a.x, (uint32_t)arg); r.y = f8Pre4<WM>(a.y, (uint32_t)arg);
-    r.z = f8Pre4<WM>(a.z, (uint32_t)arg); r.w = f8Pre4<WM>(a.w, (uint32_t)arg);
+    const uint32_t s = (uint32_t)arg & 0xffu;
+    u32x4 r; r.x = byteMul4(a.x, s); r.y = byteMul4(a.y, s); r.z = byteMul4(a.z, s); r.w = byteMul4(a.w, s);
     return r;
   }
-  static __device__ __forceinline__ u32x4 post(u32x4 a, uint64_t) { return a; }
+  static __device__ __forceinline__ u32x4 post(u32x4 a, uint64_t arg) {
+    const uint32_t n = (uint32_t)arg;
+    u32x4 r; r.x = byteDiv4<SIGNED>(a.x, n); r.y = byteDiv4<SIGNED>(a.y, n); r.z = byteDiv4<SIGNED>(a.z, n); r.w = byteDiv4<SIGNED>(a.w, n);
+    return r;
+  }
 };
+template <int OP> struct PackOps<int8_t, OP> : BytePackOps<true, OP> {};
+template <int OP> struct PackOps<uint8_t, OP> : BytePackOps<false, OP> {};
+
 template <typename T, int OP> __device__ __forceinline__ u32x4 packRed(u32x4 a, u32x4 b) { return PackOps<T, OP>::red(a, b); }
 template <typename T> __device__ __forceinline__ u32x4 packPre(u32x4 a, uint64_t arg) { return PackOps<T, RA_OP_SUM>::pre(a, arg); }
 template <typename T> __device__ __forceinline__ u32x4 packPost(u32x4 a, uint64_t arg) { return PackOps<T, RA_OP_SUM>::post(a, arg); }
+
+// The fold of one pack position over its sources, left to right: src[0] (op) src[1] (op) ... (op) src[ns-1], entries from
+// ns on ignored; the source at preIdx is pre-multiplied (FuncPreMulSum), the result post-divided when `post`
+// (FuncSumPostDiv).  NMAX is a compile-time bound, so the source array is only ever indexed by constants.
+template <typename T, int OP> struct PackFold {
+  template <int NMAX>
+  static __device__ __forceinline__ u32x4 fold(const u32x4 (&src)[NMAX], int ns, int preIdx, uint64_t opArg, bool post) {
+    u32x4 acc = src[0];
+    if (OP == RA_OP_PREMULSUM && preIdx == 0) acc = packPre<T>(acc, opArg);
+#pragma unroll
+    for (int j = 1; j < NMAX; j++)
+      if (j < ns) {
+        u32x4 x = src[j];
+        if (OP == RA_OP_PREMULSUM && preIdx == j) x = packPre<T>(x, opArg);
+        acc = packRed<T, OP>(acc, x);
+      }
+    if (OP == RA_OP_SUMPOSTDIV && post) acc = packPost<T>(acc, opArg);
+    return acc;
+  }
+};
+// The 8-bit floats keep the running value as floats that are rounded onto the 8-bit grid after every operation
+// (f8_math.h: the same bits as the reference's encode after every pairwise operation, src/device/reduce_kernel.h:267-272,
+// at about half the instructions) and encode once, when the fold is over.  One dword (four elements) at a time through
+// all its sources, so that no more than eight floats are live.
+template <int WM, int OP> struct PackFold<f8_t<WM>, OP> {
+  static constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+  template <int NMAX>
+  static __device__ __forceinline__ u32x4 fold(const u32x4 (&src)[NMAX], int ns, int preIdx, uint64_t opArg, bool) {
+    const float k = OP == RA_OP_PREMULSUM ? f8Decode<WM>((uint32_t)opArg) : 1.0f;
+    u32x4 out;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      float st[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        st[i] = f8Decode<WM>(src[0][w] >> (8 * i));
+        if (OP == RA_OP_PREMULSUM && preIdx == 0) st[i] = f8Quantize<WM>(st[i] * k);
+      }
+#pragma unroll
+      for (int j = 1; j < NMAX; j++)
+        if (j < ns) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            float x = f8Decode<WM>(src[j][w] >> (8 * i));
+            if (OP == RA_OP_PREMULSUM && preIdx == j) x = f8Quantize<WM>(x * k);
+            const float v = Elem<float, R>::red(st[i], x);
+            st[i] = (R == RA_OP_MAX || R == RA_OP_MIN) ? v : f8Quantize<WM>(v);   // a maximum of grid values lies on the grid
+          }
+        }
+      out[w] = f8EncodeOnGrid<WM>(st[0]) | (f8EncodeOnGrid<WM>(st[1]) << 8) | (f8EncodeOnGrid<WM>(st[2]) << 16) |
+               (f8EncodeOnGrid<WM>(st[3]) << 24);
+      __builtin_amdgcn_sched_barrier(0);       // one dword after the other: keeps the float temporaries of one dword apart from the next one's
+    }
+    return out;
+  }
+};
 
 // Global-address-space accesses (never flat): nontemporal 16-byte loads and stores.
 typedef __attribute__((address_space(1))) const u32x4 gc_u32x4;
@@ -252,6 +326,11 @@ __device__ __forceinline__ void stSys(u32x4* p, u32x4 v) {
 // dst[k][i] = post( pre?(src[0][i]) (op) src[1][i] (op) ... ), folded left to right.
 // `preIdx` is the one source that gets the pre-multiply (this rank's own input; the
 // others arrive already scaled), or -1.
+//
+// An argument block lives in registers.  That only works while every access to src[] / dst[] uses an index the
+// compiler knows: an index computed at run time would force the arrays into per-lane scratch memory, and no kernel of
+// this library has a stack frame (see tests/test_stack_size.py).  So the arrays are filled and read in loops that are
+// fully unrolled over RA_MAX_SRCS with the run-time count as a predicate (RC_EACH below), never `for (j < ns)`.
 struct RcArgs {
   const char* src[RA_MAX_SRCS];
   char* dst[RA_MAX_SRCS];
@@ -261,6 +340,10 @@ struct RcArgs {
                    // of them); the rest are windows or peers' buffers, written with write-through stores
   uint64_t opArg;
 };
+// for (J = FIRST; J < COUNT; J++) BODY with J a compile-time constant in every copy of BODY
+#define RC_EACH(J, FIRST, COUNT, ...)                          \
+  _Pragma("unroll") for (int J = (FIRST); J < RA_MAX_SRCS; J++) \
+    if (J < (COUNT)) { __VA_ARGS__ }
 
 // Values that are the same in every lane but reach us through memory or a call (so the
 // compiler cannot know it) are moved to scalar registers: addresses then take the
@@ -330,26 +413,19 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
     // workgroup has just read: no branch, no traffic to speak of)
     auto load = [&](u32x4 (&v)[NSA][U], size_t at, bool real) {
 #pragma unroll
-      for (int j = 0; j < NSA; j++)
+      for (int u = 0; u < U; u++)
 #pragma unroll
-        for (int u = 0; u < U; u++) v[j][u] = ldAt(s[j] + at * 16, real ? lane16 + (uint32_t)u * row : 0u);
+        for (int j = 0; j < NSA; j++) v[j][u] = ldAt(s[j] + at * 16, real ? lane16 + (uint32_t)u * row : 0u);
     };
+    // one pack position at a time through all its sources (loads are issued in the same order, so the first fold
+    // waits for the first NS loads only)
     auto fold = [&](u32x4 (&cur)[NSA][U], size_t at) {
-      if (OP == RA_OP_PREMULSUM) {
 #pragma unroll
-        for (int j = 0; j < NSA; j++)
-          if (j == preIdx) {
+      for (int u = 0; u < U; u++) {
+        u32x4 col[NSA];
 #pragma unroll
-            for (int u = 0; u < U; u++) cur[j][u] = packPre<T>(cur[j][u], opArg);
-          }
-      }
-#pragma unroll
-      for (int j = 1; j < NSA; j++)
-#pragma unroll
-        for (int u = 0; u < U; u++) cur[0][u] = packRed<T, OP>(cur[0][u], cur[j][u]);
-      if (OP == RA_OP_SUMPOSTDIV && post) {
-#pragma unroll
-        for (int u = 0; u < U; u++) cur[0][u] = packPost<T>(cur[0][u], opArg);
+        for (int j = 0; j < NSA; j++) col[j] = cur[j][u];
+        cur[0][u] = PackFold<T, OP>::template fold<NSA>(col, NSA, preIdx, opArg, post);
       }
 #pragma unroll
       for (int k = 0; k < NDA; k++) storeTo(d[k], k >= LOC, cur[0], at * 16);
@@ -380,46 +456,31 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
   } else {
     for (; base + tile <= npacks; base += tileStep) {
       const size_t b16 = base * 16;
+      u32x4 t[U][RA_MAX_SRCS];
+#pragma unroll
+      for (int u = 0; u < U; u++) t[u][0] = ldAt((uint64_t)uniformPtr(a.src[0]) + b16, lane16 + (uint32_t)u * row);
+      RC_EACH(j, 1, ns,
+        const uint64_t sj = (uint64_t)uniformPtr(a.src[j]) + b16;
+        _Pragma("unroll") for (int u = 0; u < U; u++) t[u][j] = ldAt(sj, lane16 + (uint32_t)u * row);
+      )
       u32x4 acc[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        acc[u] = ldAt((uint64_t)uniformPtr(a.src[0]) + b16, lane16 + (uint32_t)u * row);
-        if (OP == RA_OP_PREMULSUM && preIdx == 0) acc[u] = packPre<T>(acc[u], opArg);
-      }
-      for (int j = 1; j < ns; j++) {
-        const uint64_t sj = (uint64_t)uniformPtr(a.src[j]) + b16;
-        u32x4 t[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) t[u] = ldAt(sj, lane16 + (uint32_t)u * row);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-          if (OP == RA_OP_PREMULSUM && preIdx == j) t[u] = packPre<T>(t[u], opArg);
-          acc[u] = packRed<T, OP>(acc[u], t[u]);
-        }
-      }
-      if (OP == RA_OP_SUMPOSTDIV && post) {
-#pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], opArg);
-      }
-      for (int k = 0; k < nd; k++) storeTo((uint64_t)uniformPtr(a.dst[k]), k >= nLocal, acc, b16);
+      for (int u = 0; u < U; u++) acc[u] = PackFold<T, OP>::template fold<RA_MAX_SRCS>(t[u], ns, preIdx, opArg, post);
+      RC_EACH(k, 0, nd, storeTo((uint64_t)uniformPtr(a.dst[k]), k >= nLocal, acc, b16);)
     }
   }
   // Ragged end: the one tile that is not full, one pack per thread per pass.  Only the
   // workgroup whose walk reaches it handles it.
   if (base < npacks) {
     for (size_t i = base + tid; i < npacks; i += nthrU) {
-      u32x4 acc = ldPack((const u32x4*)uniformPtr(a.src[0]) + i);
-      if (OP == RA_OP_PREMULSUM && preIdx == 0) acc = packPre<T>(acc, opArg);
-      for (int j = 1; j < ns; j++) {
-        u32x4 t = ldPack((const u32x4*)uniformPtr(a.src[j]) + i);
-        if (OP == RA_OP_PREMULSUM && preIdx == j) t = packPre<T>(t, opArg);
-        acc = packRed<T, OP>(acc, t);
-      }
-      if (OP == RA_OP_SUMPOSTDIV && post) acc = packPost<T>(acc, opArg);
-      for (int k = 0; k < nd; k++) {
+      u32x4 t[RA_MAX_SRCS];
+      t[0] = ldPack((const u32x4*)uniformPtr(a.src[0]) + i);
+      RC_EACH(j, 1, ns, t[j] = ldPack((const u32x4*)uniformPtr(a.src[j]) + i);)
+      const u32x4 acc = PackFold<T, OP>::template fold<RA_MAX_SRCS>(t, ns, preIdx, opArg, post);
+      RC_EACH(k, 0, nd,
         if (k >= nLocal) stSys((u32x4*)uniformPtr(a.dst[k]) + i, acc);
         else stPack((u32x4*)uniformPtr(a.dst[k]) + i, acc);
-      }
+      )
     }
   }
 }
@@ -440,27 +501,29 @@ template <typename T> __device__ __forceinline__ void stSysElem(T* p, T v) {
 template <typename T, int OP>
 __device__ __forceinline__ void rcElems(const RcArgs& a, size_t nelem, size_t first, size_t step, int tid) {
   constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
+  const int ns = uniformInt(a.ns), nd = uniformInt(a.nd), nLocal = uniformInt(a.nLocal), preIdx = uniformInt(a.preIdx);
+  const uint64_t opArg = uniform64(a.opArg);
   for (size_t i = first + tid; i < nelem; i += step) {
     T acc = ((const T*)a.src[0])[i];
-    if (OP == RA_OP_PREMULSUM && a.preIdx == 0) acc = Scale<T>::pre(acc, a.opArg);
-    for (int j = 1; j < a.ns; j++) {
+    if (OP == RA_OP_PREMULSUM && preIdx == 0) acc = Scale<T>::pre(acc, opArg);
+    RC_EACH(j, 1, ns,
       T t = ((const T*)a.src[j])[i];
-      if (OP == RA_OP_PREMULSUM && a.preIdx == j) t = Scale<T>::pre(t, a.opArg);
+      if (OP == RA_OP_PREMULSUM && preIdx == j) t = Scale<T>::pre(t, opArg);
       acc = Elem<T, R>::red(acc, t);
-    }
-    if (OP == RA_OP_SUMPOSTDIV && a.post) acc = Scale<T>::post(acc, a.opArg);
-    for (int k = 0; k < a.nd; k++) {
-      if (k >= a.nLocal) stSysElem<T>((T*)a.dst[k] + i, acc);
+    )
+    if (OP == RA_OP_SUMPOSTDIV && a.post) acc = Scale<T>::post(acc, opArg);
+    RC_EACH(k, 0, nd,
+      if (k >= nLocal) stSysElem<T>((T*)a.dst[k] + i, acc);
       else ((T*)a.dst[k])[i] = acc;
-    }
+    )
   }
 }
 
 __device__ __forceinline__ bool rcAligned(const RcArgs& a) {
   uintptr_t m = 0;
-  for (int j = 0; j < a.ns; j++) m |= (uintptr_t)a.src[j];
-  for (int k = 0; k < a.nd; k++) m |= (uintptr_t)a.dst[k];
-  return (m & 15) == 0;
+  RC_EACH(j, 0, a.ns, m |= (uintptr_t)a.src[j];)
+  RC_EACH(k, 0, a.nd, m |= (uintptr_t)a.dst[k];)
+  return (uniform64(m) & 15) == 0;
 }
 
 // One (source count, destination count) case: full tiles of nthr*U packs are dealt round-robin to the `nparts`
@@ -477,63 +540,82 @@ __device__ __forceinline__ void rcCase(const RcArgs& a, size_t npacks, int tid, 
 // Work-shared reduce-copy of `nelem` elements.  `part` of `nparts` workgroups take part
 // (the collectives use one workgroup: part 0 of 1; the local kernels use the whole grid).
 // The (sources, destinations, local destinations) shapes the schedules use at 2, 4 and 8 ranks get the pipelined loop
-// (sources x packs per thread = 8 loads, 128 B, per tile and thread in every case): one destination, local (local
-// kernels, reduce-scatter and reduce) or remote (ring and chain hops); as many destinations as sources with the first
-// one local (the all-pairs reducer; the ring's and chain's last reducing hop).  Every other shape takes the plain loop.
-template <typename T, int OP, bool PIPE>
+// (sources x packs per thread = 8 loads, 128 B, per tile and thread in every case); every other shape takes the plain
+// loop.  Everything is inlined into its caller, so a call site names the family of shapes it can produce (SH) and only
+// those loops are built there.
+enum {
+  RC_LOCAL,      // local kernels: 1, 2, 4 or 8 sources into one local destination
+  RC_SEND,       // one source into one remote destination (scatter with a pre-multiply, ring seed, chain leaf, reduce push)
+  RC_HOP,        // local + received into one remote destination (ring and chain middle hops)
+  RC_HOP_KEEP,   // local + received into the receive buffer and one remote destination (ring: own piece; chain: root)
+  RC_HOP_END,    // local + received into the receive buffer (ring reduce-scatter: last hop)
+  RC_FOLD_ALL,   // n sources into the receive buffer and n - 1 remote destinations (the all-pairs reducer)
+  RC_FOLD_ONE,   // n sources into the receive buffer (reduce-scatter and reduce on the all-pairs links, one exchange)
+};
+template <int SH> __device__ __forceinline__ constexpr bool rcHas(int ns, int nd, int loc) {
+  return SH == RC_LOCAL      ? (nd == 1 && loc == 1 && (ns == 1 || ns == 2 || ns == 4 || ns == 8))
+         : SH == RC_SEND     ? (ns == 1 && nd == 1 && loc == 0)
+         : SH == RC_HOP      ? (ns == 2 && nd == 1 && loc == 0)
+         : SH == RC_HOP_KEEP ? (ns == 2 && nd == 2 && loc == 1)
+         : SH == RC_HOP_END  ? (ns == 2 && nd == 1 && loc == 1)
+         : SH == RC_FOLD_ALL ? (loc == 1 && ns == nd && (ns == 2 || ns == 4 || ns == 8))
+                             : (loc == 1 && nd == 1 && (ns == 2 || ns == 4 || ns == 8));
+}
+template <typename T, int OP, bool PIPE, int SH>
 __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int tid, int nthr, int part, int nparts) {
   if (nelem == 0 || a.nd == 0) return;
   if (rcAligned(a)) {
     const size_t npacks = nelem * sizeof(T) / 16;
     const int shape = __builtin_amdgcn_readfirstlane(a.ns * 256 + a.nd * 16 + a.nLocal);
-    switch (shape) {
-      case 1 * 256 + 1 * 16 + 0: rcCase<T, OP, 0, 1, 8, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 1 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 1, 8, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 2 * 256 + 1 * 16 + 0: rcCase<T, OP, 0, 2, 4, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 2 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 2, 4, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 4 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 4, 2, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 8 * 256 + 1 * 16 + 1: rcCase<T, OP, 1, 8, 1, 1, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 2 * 256 + 2 * 16 + 1: rcCase<T, OP, 1, 2, 4, 2, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 4 * 256 + 4 * 16 + 1: rcCase<T, OP, 1, 4, 2, 4, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      case 8 * 256 + 8 * 16 + 1: rcCase<T, OP, 1, 8, 1, 8, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-      default: rcCase<T, OP, 0, 0, 2, 0, PIPE>(a, npacks, tid, nthr, part, nparts); break;
-    }
-    const size_t done = npacks * (16 / sizeof(T));
-    if (done < nelem && part == 0) rcElems<T, OP>(a, nelem, done, nthr, tid);
+    bool done = false;
+    // (the 8-bit floats are bound by their conversions, not by memory: they take the plain loop, one pack per thread, whose
+    // code is a fraction of the pipelined loops' and leaves the registers to the float temporaries)
+#define RC_TRY(NS, U, ND, LOC)                                                                  \
+    if constexpr (rcHas<SH>(NS, ND, LOC) && !IsF8<T>::value)                                      \
+      if (!done && shape == NS * 256 + ND * 16 + LOC) { rcCase<T, OP, LOC, NS, U, ND, PIPE>(a, npacks, tid, nthr, part, nparts); done = true; }
+    RC_TRY(1, 8, 1, 0) RC_TRY(1, 8, 1, 1) RC_TRY(2, 4, 1, 0) RC_TRY(2, 4, 1, 1) RC_TRY(4, 2, 1, 1) RC_TRY(8, 1, 1, 1)
+    RC_TRY(2, 4, 2, 1) RC_TRY(4, 2, 4, 1) RC_TRY(8, 1, 8, 1)
+#undef RC_TRY
+    if (!done) rcCase<T, OP, 0, 0, IsF8<T>::value ? 1 : 2, 0, PIPE>(a, npacks, tid, nthr, part, nparts);
+    const size_t fin = npacks * (16 / sizeof(T));
+    if (fin < nelem && part == 0) rcElems<T, OP>(a, nelem, fin, nthr, tid);
   } else {
     rcElems<T, OP>(a, nelem, (size_t)part * nthr, (size_t)nparts * nthr, tid);
   }
 }
 
-// The two entry points the collective schedules call, kept out of line so that each
-// (type, op) pair carries one copy of the loops however many schedule steps use them.
-template <typename T, int OP>
-__device__ __noinline__ void rcWG(const RcArgs& a, size_t nelem, int tid, int nthr) {
-  reduceCopy<T, OP, true>(a, nelem, tid, nthr, 0, 1);
+// The entry point the collective schedules call: one workgroup, pipelined loops.
+template <typename T, int OP, int SH>
+__device__ __forceinline__ void rcWG(const RcArgs& a, size_t nelem, int tid, int nthr) {
+  reduceCopy<T, OP, true, SH>(a, nelem, tid, nthr, 0, 1);
 }
-// One source to a.nd destinations, any element type (1, 2, 3, 4, 7 and 8 destinations are what the all-gather,
-// broadcast, ring and chain schedules ask for at 2, 4 and 8 ranks; the first one may be local).
-template <int LOC>
+// One source to a.nd destinations, any element type.  Call sites name their family of shapes:
+enum {
+  CP_END,      // into the receive buffer only (last hop of a ring or chain, fallback copies)
+  CP_FWD,      // into the receive buffer and on to one remote destination (ring and chain forwarding hops)
+  CP_SPREAD,   // into 1, 2, 3, 4, 7 or 8 destinations of which the first may be local (all-gather, broadcast, one exchange)
+};
+template <int CS, int LOC>
 static __device__ __forceinline__ void copyShapes(const RcArgs& a, size_t np, int tid, int nthr) {
-  switch (__builtin_amdgcn_readfirstlane(a.nd)) {
-    case 1: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 1>(a, np, tid, nthr, 0, 1); break;
-    case 2: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 2>(a, np, tid, nthr, 0, 1); break;
-    case 3: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 3>(a, np, tid, nthr, 0, 1); break;
-    case 4: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 4>(a, np, tid, nthr, 0, 1); break;
-    case 7: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 7>(a, np, tid, nthr, 0, 1); break;
-    case 8: rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, 8>(a, np, tid, nthr, 0, 1); break;
-    default: rcCase<int8_t, RA_OP_SUM, 0, 0, 2, 0>(a, np, tid, nthr, 0, 1); break;
-  }
+  const int nd = __builtin_amdgcn_readfirstlane(a.nd);
+  bool done = false;
+#define CP_TRY(ND)                                                                                              \
+  if constexpr (CS == CP_SPREAD || (CS == CP_END && ND == 1 && LOC == 1) || (CS == CP_FWD && ND == 2 && LOC == 1)) \
+    if (!done && nd == ND) { rcCase<int8_t, RA_OP_SUM, LOC, 1, 8, ND>(a, np, tid, nthr, 0, 1); done = true; }
+  CP_TRY(1) CP_TRY(2) CP_TRY(3) CP_TRY(4) CP_TRY(7) CP_TRY(8)
+#undef CP_TRY
+  if (!done) rcCase<int8_t, RA_OP_SUM, 0, 0, 2, 0>(a, np, tid, nthr, 0, 1);
 }
-static __device__ __noinline__ void copyWG(const RcArgs& a, size_t nbytes, int tid, int nthr) {
+template <int CS>
+static __device__ __forceinline__ void copyWG(const RcArgs& a, size_t nbytes, int tid, int nthr) {
   if (nbytes == 0 || a.nd == 0) return;
   if (rcAligned(a)) {
     const int nLocal = __builtin_amdgcn_readfirstlane(a.nLocal);
-    if (nLocal == 0) copyShapes<0>(a, nbytes / 16, tid, nthr);
-    else if (nLocal == 1) copyShapes<1>(a, nbytes / 16, tid, nthr);
+    if (nLocal == 0 && CS == CP_SPREAD) copyShapes<CS, 0>(a, nbytes / 16, tid, nthr);
+    else if (nLocal == 1) copyShapes<CS, 1>(a, nbytes / 16, tid, nthr);
     else rcCase<int8_t, RA_OP_SUM, 0, 0, 2, 0>(a, nbytes / 16, tid, nthr, 0, 1);
-    const size_t done = nbytes & ~(size_t)15;
-    if (done < nbytes) rcElems<int8_t, RA_OP_SUM>(a, nbytes, done, nthr, tid);
+    const size_t fin = nbytes & ~(size_t)15;
+    if (fin < nbytes) rcElems<int8_t, RA_OP_SUM>(a, nbytes, fin, nthr, tid);
   } else {
     rcElems<int8_t, RA_OP_SUM>(a, nbytes, 0, nthr, tid);
   }
@@ -593,12 +675,12 @@ __device__ __forceinline__ size_t pairRows(const uint64_t* sIn, const uint64_t* 
 
 // WT: the destinations are windows (write-through stores: the scatter role); otherwise local memory (the gather role).
 template <bool WT>
-static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn, int tid, int nthr) {
+static __device__ __forceinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn, int tid, int nthr) {
   const int np = __builtin_amdgcn_readfirstlane(a.ns);
   const size_t nbytes = uniform64(nbytesIn);
   if (nbytes == 0 || np == 0) return;
   uintptr_t m = 0;
-  for (int j = 0; j < np; j++) m |= (uintptr_t)a.src[j] | (uintptr_t)a.dst[j];
+  RC_EACH(j, 0, np, m |= (uintptr_t)a.src[j] | (uintptr_t)a.dst[j];)
   const bool aligned = (uniform64(m) & 15) == 0;
   size_t done = 0;
   if (aligned) {
@@ -608,8 +690,8 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
     uint64_t s[RA_MAX_SRCS], d[RA_MAX_SRCS];
 #pragma unroll
     for (int j = 0; j < RA_MAX_SRCS; j++) {
-      s[j] = uniform64((uint64_t)a.src[j < np ? j : 0]);
-      d[j] = uniform64((uint64_t)a.dst[j < np ? j : 0]);
+      s[j] = uniform64((uint64_t)(j < np ? a.src[j] : a.src[0]));
+      d[j] = uniform64((uint64_t)(j < np ? a.dst[j] : a.dst[0]));
     }
     // spans of rows x pairs = up to 8 loads per thread, then what is left one row of every pair at a time
     switch (np) {
@@ -619,6 +701,7 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
       case 4: done = pairRows<WT, 4, 2>(s, d, nbytes, lane16, row); break;
       default: break;
     }
+#pragma unroll
     for (int j = 0; j < RA_MAX_SRCS; j++) { s[j] += done; d[j] += done; }
     switch (np) {
       case 1: done += pairRows<WT, 1, 1>(s, d, nbytes - done, lane16, row); break;
@@ -633,14 +716,14 @@ static __device__ __noinline__ void pairCopyWG(const RcArgs& a, size_t nbytesIn,
   }
   // what is left (ragged end, or everything when a pointer is unaligned): pair by pair, bytes
   if (done < nbytes) {
-    for (int j = 0; j < np; j++) {
+    RC_EACH(j, 0, np,
       const int8_t* sj = (const int8_t*)uniformPtr(a.src[j]);
       int8_t* dj = (int8_t*)uniformPtr(a.dst[j]);
       for (size_t i = done + tid; i < nbytes; i += nthr) {
         if (WT) stSysElem<int8_t>(dj + i, sj[i]);
         else dj[i] = sj[i];
       }
-    }
+    )
   }
 }
 
@@ -661,9 +744,13 @@ template <typename T> __device__ __forceinline__ uint64_t loadScalarArg(const vo
 // ------------------------------------------------------------------ local kernels
 // One rank (src/device/onerank.cu) and the exported N-source reduce-copy.
 template <typename T, int OP>
-__global__ __launch_bounds__(1024) void raLocalKernel(RcArgs a, size_t nelem, const void* opArgPtr) {
-  if (OP == RA_OP_PREMULSUM && opArgPtr) a.opArg = loadScalarArg<T>(opArgPtr);
-  reduceCopy<T, OP, false>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(1024) void raLocalKernel(RcArgs k, size_t nelem, const void* opArgPtr) {
+  RcArgs a;                        // a copy with constant indices: the kernel-argument block itself is read-only memory
+#pragma unroll
+  for (int j = 0; j < RA_MAX_SRCS; j++) { a.src[j] = k.src[j]; a.dst[j] = k.dst[j]; }
+  a.ns = k.ns; a.nd = k.nd; a.preIdx = k.preIdx; a.post = k.post; a.nLocal = k.nLocal;
+  a.opArg = (OP == RA_OP_PREMULSUM && opArgPtr) ? loadScalarArg<T>(opArgPtr) : k.opArg;
+  reduceCopy<T, OP, false, RC_LOCAL>(a, nelem, threadIdx.x, blockDim.x, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ inter-GPU protocol
@@ -677,7 +764,8 @@ __device__ __forceinline__ void drainVmem() { asm volatile("s_waitcnt vmcnt(0)" 
 
 // Waits until *f >= want.  Every wait is bounded and watches the communicator's abort request; once one has given up
 // (*aborted, a flag of the workgroup), the later ones return at once.
-static __device__ __forceinline__ void raSpin(const RaDevComm* comm, int* aborted, const uint64_t* f, uint64_t want) {
+typedef __attribute__((address_space(3))) int LdsInt;
+static __device__ __forceinline__ void raSpin(const RaDevComm* comm, LdsInt* aborted, const uint64_t* f, uint64_t want) {
   if (*aborted) return;
   const uint64_t t0 = wall_clock64();
   uint32_t spins = 0;
@@ -711,10 +799,16 @@ struct ChanShared {
   // tuneFlags 32: ticks thread 0 spent waiting / in the body / draining / posting, steps; stamps of the step under way
   uint64_t tk[5], ts[4];
 };
+// The per-channel state lives in LDS and is only ever reached through LDS pointers (never generic ones), so that every
+// access is a ds_ instruction and none can fall into another aperture.
+typedef __attribute__((address_space(3))) ChanShared LdsChan;
+#define RA_LDS_CHAN(var) ((LdsChan*)&(var))
 
+// Everything a workgroup knows about the channel it is serving.  All members are the same in every lane; the
+// kernels are built without calls, so the object never leaves the registers.
 struct Ctx {
   const RaDevComm* comm;
-  ChanShared* sh;
+  LdsChan* sh;
   int ch, tid, nthr, rank, nRanks;
   uint32_t stepBytes;
   int auxRecv = 0, auxSend = 0;   // this step carries the once-per-launch words (first step of a workgroup only)
@@ -724,48 +818,74 @@ struct Ctx {
   }
   // Slot I fill next on the FIFO towards `peer` (it lives in peer's window).
   __device__ __forceinline__ char* sendSlot(int peer, int kind) const {
-    return comm->win[peer] + raDataOffset(comm->lay, ch, peer, rank, kind) +
-           (sh->sendStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
+    return uniformPtr(comm->win[peer] + raDataOffset(comm->lay, ch, peer, rank, kind) +
+                      (sh->sendStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes);
   }
   // Slot I drain next on the FIFO from `peer` (it lives in my window).
   __device__ __forceinline__ const char* recvSlot(int peer, int kind) const {
-    return comm->win[rank] + raDataOffset(comm->lay, ch, rank, peer, kind) +
-           (sh->recvStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes;
+    return uniformPtr((const char*)comm->win[rank] + raDataOffset(comm->lay, ch, rank, peer, kind) +
+                      (sh->recvStep[peer][kind] % comm->lay.nSlots) * (size_t)comm->lay.slotBytes);
   }
 
-  __device__ void init(const RaDevComm* c, ChanShared* s, int channel, uint32_t stepBytes_) {
-    stepBytes = stepBytes_;
-    comm = c; sh = s; ch = channel; tid = threadIdx.x; nthr = blockDim.x; rank = c->rank; nRanks = c->nRanks;
-    const int n = nRanks * RA_NKINDS;
+  // Loads the channel's step counters into its LDS block.  The caller puts a barrier behind the last init.
+  static __device__ __forceinline__ void loadChannel(const RaDevComm* c, LdsChan* s, int channel) {
+    const int tid = threadIdx.x;
+    const int n = c->nRanks * RA_NKINDS;
     if (tid < n) {
-      const size_t ix = (size_t)ch * n + tid;
-      sh->sendStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->sendStep[ix];
-      sh->recvStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->recvStep[ix];
+      const size_t ix = (size_t)channel * n + tid;
+      s->sendStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->sendStep[ix];
+      s->recvStep[tid / RA_NKINDS][tid % RA_NKINDS] = c->recvStep[ix];
     }
     if (tid == 0) {
-      sh->aborted = 0;
-      for (int k = 0; k < RA_NKINDS; k++) { sh->sendDirty[k] = 0; sh->recvDirty[k] = 0; }
+      s->aborted = 0;
+      for (int k = 0; k < RA_NKINDS; k++) { s->sendDirty[k] = 0; s->recvDirty[k] = 0; }
     }
-    if (tid < RA_MAX_RANKS) { sh->auxIn[tid] = 0; sh->auxOut[tid] = 0; sh->directBase[tid] = 0; }
-    if (tid < 5) sh->tk[tid] = 0;
+    if (tid < RA_MAX_RANKS) { s->auxIn[tid] = 0; s->auxOut[tid] = 0; s->directBase[tid] = 0; }
+    if (tid < 5) s->tk[tid] = 0;
+  }
+  __device__ __forceinline__ void init(const RaDevComm* c, LdsChan* s, int channel, uint32_t stepBytes_) {
+    stepBytes = stepBytes_;
+    comm = c; sh = s; ch = uniformInt(channel); tid = threadIdx.x; nthr = blockDim.x;
+    rank = uniformInt(c->rank); nRanks = uniformInt(c->nRanks);
+    loadChannel(c, s, channel);
     __syncthreads();
   }
-  // Persist the step counters this workgroup advanced.
-  __device__ void finish(int role = 0) {
-    if ((comm->tuneFlags & 32) && tid == 0 && role < 3)
+  // The workgroup turns to another of its channels (two-rank role pairing: a scatter or gather workgroup serves two).
+  __device__ __forceinline__ void select(LdsChan* s, int channel) { sh = s; ch = uniformInt(channel); }
+
+  // Persists the step counters this workgroup advanced on channel (s, channel).
+  static __device__ __forceinline__ void storeChannel(const RaDevComm* c, LdsChan* s, int channel, int role) {
+    const int tid = threadIdx.x;
+    if ((c->tuneFlags & 32) && tid == 0 && role < 3)
       for (int k = 0; k < 5; k++)
-        __hip_atomic_fetch_add(&comm->stats[8 + role * 5 + k], sh->tk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int n = nRanks * RA_NKINDS;
+        __hip_atomic_fetch_add(&c->stats[8 + role * 5 + k], s->tk[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = c->nRanks * RA_NKINDS;
     if (tid < n) {
       const int p = tid / RA_NKINDS, k = tid % RA_NKINDS;
-      const size_t ix = (size_t)ch * n + tid;
-      if (sh->sendDirty[k] >> p & 1) comm->sendStep[ix] = sh->sendStep[p][k];
-      if (sh->recvDirty[k] >> p & 1) comm->recvStep[ix] = sh->recvStep[p][k];
+      const size_t ix = (size_t)channel * n + tid;
+      if (s->sendDirty[k] >> p & 1) c->sendStep[ix] = s->sendStep[p][k];
+      if (s->recvDirty[k] >> p & 1) c->recvStep[ix] = s->recvStep[p][k];
     }
   }
+  __device__ __forceinline__ void finish(int role = 0) {
+    __syncthreads();
+    storeChannel(comm, sh, ch, role);
+  }
 
-  __device__ void spin(const uint64_t* f, uint64_t want) { raSpin(comm, &sh->aborted, f, want); }
+  // Fresh copies of the lane number and of the communicator pointer that the compiler cannot trace back to the
+  // originals: what a step derives from them (every lane's flag addresses, window layout fields) is then computed
+  // where it is used instead of once in front of the round loop, where it would stay live across the copy loops and,
+  // with their 128 registers in use, end up in scratch memory.
+  static __device__ __forceinline__ int freshLane(int v) { asm volatile("" : "+v"(v)); return v; }
+  static __device__ __forceinline__ const RaDevComm* freshComm(const RaDevComm* c) {
+    const uint64_t u = (uint64_t)c;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const RaDevComm*)(((uint64_t)hi << 32) | lo);
+  }
+  __device__ __forceinline__ uint64_t* flagOf(const RaDevComm* c, int owner, int which, int peer, int kind) const {
+    return (uint64_t*)(c->win[owner] + raFlagOffset(c->lay, which, ch, peer, kind));
+  }
 
   // One protocol step.  recvMask/sendMask: bit p set = peer p takes part.  Lane p of wave 0
   // waits for peer p's data (tail), lane 16+p waits for a free slot towards peer p (head).
@@ -773,77 +893,87 @@ struct Ctx {
   // fills sendSlot()s.  Returns false once the communicator was aborted.
   template <class F>
   __device__ __forceinline__ bool step(uint32_t recvMask, int rk, uint32_t sendMask, int sk, F&& body) {
-    const bool timed = (comm->tuneFlags & 32) && tid == 0;
-    if (timed) sh->ts[0] = wall_clock64();
-    if (tid < RA_MAX_RANKS) {
-      if (recvMask >> tid & 1) {
-        spin(flag(rank, 0, tid, rk), sh->recvStep[tid][rk] + 1);
-        if (auxRecv) sh->auxIn[tid] = ldFlag(flag(rank, 2 + (int)(sh->recvStep[tid][rk] % comm->lay.nSlots), tid, rk));
-        if (!(comm->tuneFlags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-      }
-    } else if (tid < 2 * RA_MAX_RANKS) {
-      const int p = tid - RA_MAX_RANKS;
-      if (sendMask >> p & 1) {
-        const uint64_t need = sh->sendStep[p][sk] + 1;   // slots published once this one is
-        if (need > (uint64_t)comm->lay.nSlots) spin(flag(rank, 1, p, sk), need - comm->lay.nSlots);
-      }
-    }
-    if (tid < 64) drainVmem();
-    __syncthreads();
-    if (timed) sh->ts[1] = wall_clock64();
-    const bool ok = !sh->aborted;
-    // tuneFlags 64: every step that consumes data dawdles (about 0.1 ms) before its body, so that the senders run
-    // ahead until they are held back by the credits: the slow-consumer case, which fast reducers never produce.
-    if ((comm->tuneFlags & 64) && recvMask)
-      for (int i = 0; i < 32; i++) __builtin_amdgcn_s_sleep(127);
-    if (ok) body();
-    if (timed) sh->ts[2] = wall_clock64();
-    drainVmem();       // every wave: its loads have returned and its stores are acknowledged
-    __syncthreads();
-    if (timed) sh->ts[3] = wall_clock64();
-    if (tid < 64) {
-      // Nothing but the drain is needed before the flag.  Every byte this step handed to a peer went out as a
-      // system-scope write-through store (sc0 sc1), each wave waited for its own stores to be acknowledged (vmcnt(0))
-      // and all waves met at the barrier above, so those bytes are at their destination before the flag store is
-      // issued; the flag takes the same path behind them.  The reference posts plain stores and therefore needs the
-      // L2 write-back of __threadfence() first (prims_simple.h:168-171); here that write-back would only flush the
-      // receive-buffer lines other workgroups are still producing (measured: two ranks sharing a GPU, 1 GiB: 2.02 ms
-      // with an agent-scope release here, 1.77 ms without).  tuneFlags 8 puts the agent-scope release back,
-      // 8 + 4 a system-scope one.
-      if (sendMask && (comm->tuneFlags & 8)) {
-        if (comm->tuneFlags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        drainVmem();
-      }
-      if (tid < RA_MAX_RANKS) {
-        if (recvMask >> tid & 1) {          // slot consumed: credit to the sender (its window)
-          const uint64_t s = sh->recvStep[tid][rk] + 1;
-          sh->recvStep[tid][rk] = s;
-          if (ok) stFlag(flag(tid, 1, rank, rk), s);
+    bool ok;
+    {
+      const int t = freshLane(tid);
+      const RaDevComm* c = freshComm(comm);
+      const bool timed = (c->tuneFlags & 32) && t == 0;
+      if (timed) sh->ts[0] = wall_clock64();
+      if (t < RA_MAX_RANKS) {
+        if (recvMask >> t & 1) {
+          raSpin(c, &sh->aborted, flagOf(c, rank, 0, t, rk), sh->recvStep[t][rk] + 1);
+          if (auxRecv) sh->auxIn[t] = ldFlag(flagOf(c, rank, 2 + (int)(sh->recvStep[t][rk] % c->lay.nSlots), t, rk));
+          if (!(c->tuneFlags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
-      } else if (tid < 2 * RA_MAX_RANKS) {
-        const int p = tid - RA_MAX_RANKS;
-        if (sendMask >> p & 1) {            // slot published: tail in the receiver's window
-          const uint64_t s = sh->sendStep[p][sk] + 1;
-          sh->sendStep[p][sk] = s;
-          if (ok) {
-            // host-staged transport: tell the proxy how many bytes this slot carries, then publish
-            if (comm->netMode) stFlag(flag(p, 2 + (int)((s - 1) % comm->lay.nSlots), rank, sk), stepBytes);
-            else if (auxSend) {               // the word must be in place before the tail that announces it
-              stFlag(flag(p, 2 + (int)((s - 1) % comm->lay.nSlots), rank, sk), sh->auxOut[p]);
-              drainVmem();
+      } else if (t < 2 * RA_MAX_RANKS) {
+        const int p = t - RA_MAX_RANKS;
+        if (sendMask >> p & 1) {
+          const uint64_t need = sh->sendStep[p][sk] + 1;   // slots published once this one is
+          if (need > (uint64_t)c->lay.nSlots) raSpin(c, &sh->aborted, flagOf(c, rank, 1, p, sk), need - c->lay.nSlots);
+        }
+      }
+      if (t < 64) drainVmem();
+      __syncthreads();
+      if (timed) sh->ts[1] = wall_clock64();
+      ok = uniformInt(sh->aborted) == 0;
+      // tuneFlags 64: every step that consumes data dawdles (about 0.1 ms) before its body, so that the senders run
+      // ahead until they are held back by the credits: the slow-consumer case, which fast reducers never produce.
+      if ((c->tuneFlags & 64) && recvMask)
+        for (int i = 0; i < 32; i++) __builtin_amdgcn_s_sleep(127);
+    }
+    if (ok) body();
+    {
+      const int t = freshLane(tid);
+      const RaDevComm* c = freshComm(comm);
+      const bool timed = (c->tuneFlags & 32) && t == 0;
+      if (timed) sh->ts[2] = wall_clock64();
+      drainVmem();       // every wave: its loads have returned and its stores are acknowledged
+      __syncthreads();
+      if (timed) sh->ts[3] = wall_clock64();
+      if (t < 64) {
+        // Nothing but the drain is needed before the flag.  Every byte this step handed to a peer went out as a
+        // system-scope write-through store (sc0 sc1), each wave waited for its own stores to be acknowledged (vmcnt(0))
+        // and all waves met at the barrier above, so those bytes are at their destination before the flag store is
+        // issued; the flag takes the same path behind them.  The reference posts plain stores and therefore needs the
+        // L2 write-back of __threadfence() first (prims_simple.h:168-171); here that write-back would only flush the
+        // receive-buffer lines other workgroups are still producing (measured: two ranks sharing a GPU, 1 GiB: 2.02 ms
+        // with an agent-scope release here, 1.77 ms without).  tuneFlags 8 puts the agent-scope release back,
+        // 8 + 4 a system-scope one.
+        if (sendMask && (c->tuneFlags & 8)) {
+          if (c->tuneFlags & 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          drainVmem();
+        }
+        if (t < RA_MAX_RANKS) {
+          if (recvMask >> t & 1) {          // slot consumed: credit to the sender (its window)
+            const uint64_t s = sh->recvStep[t][rk] + 1;
+            sh->recvStep[t][rk] = s;
+            if (ok) stFlag(flagOf(c, t, 1, rank, rk), s);
+          }
+        } else if (t < 2 * RA_MAX_RANKS) {
+          const int p = t - RA_MAX_RANKS;
+          if (sendMask >> p & 1) {            // slot published: tail in the receiver's window
+            const uint64_t s = sh->sendStep[p][sk] + 1;
+            sh->sendStep[p][sk] = s;
+            if (ok) {
+              // host-staged transport: tell the proxy how many bytes this slot carries, then publish
+              if (c->netMode) stFlag(flagOf(c, p, 2 + (int)((s - 1) % c->lay.nSlots), rank, sk), stepBytes);
+              else if (auxSend) {               // the word must be in place before the tail that announces it
+                stFlag(flagOf(c, p, 2 + (int)((s - 1) % c->lay.nSlots), rank, sk), sh->auxOut[p]);
+                drainVmem();
+              }
+              stFlag(flagOf(c, p, 0, rank, sk), s);
             }
-            stFlag(flag(p, 0, rank, sk), s);
           }
         }
+        if (t == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
       }
-      if (tid == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
-    }
-    if (timed) {
-      drainVmem();
-      const uint64_t t4 = wall_clock64();
-      sh->tk[0] += sh->ts[1] - sh->ts[0]; sh->tk[1] += sh->ts[2] - sh->ts[1]; sh->tk[2] += sh->ts[3] - sh->ts[2];
-      sh->tk[3] += t4 - sh->ts[3]; sh->tk[4] += 1;
+      if (timed) {
+        drainVmem();
+        const uint64_t t4 = wall_clock64();
+        sh->tk[0] += sh->ts[1] - sh->ts[0]; sh->tk[1] += sh->ts[2] - sh->ts[1]; sh->tk[2] += sh->ts[3] - sh->ts[2];
+        sh->tk[3] += t4 - sh->ts[3]; sh->tk[4] += 1;
+      }
     }
     // No barrier here: the counters wave 0 has just advanced are next read by wave 0 itself (the waits of the following
     // step) and by everybody only behind that step's first barrier, which wave 0 reaches after these writes.
@@ -858,7 +988,7 @@ struct Ctx {
 struct Rounds {
   size_t count, chunk, lastChunk, roundElems, nRounds;
   int n;
-  __device__ Rounds(const RaWork& w, int nRanks) {
+  __device__ __forceinline__ Rounds(const RaWork& w, int nRanks) {
     n = uniformInt(nRanks); count = uniform64(w.count); chunk = uniform64(w.chunkElems); lastChunk = uniform64(w.lastChunkElems);
     roundElems = (size_t)n * chunk;
     nRounds = (count + roundElems - 1) / roundElems;
@@ -877,15 +1007,27 @@ struct Rounds {
 
 __device__ __forceinline__ uint32_t peersMask(int nRanks, int rank) { return ((1u << nRanks) - 1u) & ~(1u << rank); }
 
+// Where peer p's registered receive buffer is mapped here, from the word W it announced (0: not mapped, use the FIFO).
+__device__ __forceinline__ uint64_t regBaseOf(const RaDevComm* comm, int p, uint64_t W) {
+  uint64_t base = 0;
+  if ((W & RA_REG_VALID) && RA_REG_IDX(W) < RA_MAX_REGS) {
+    const RaRegSlot slot = comm->regTable[p * RA_MAX_REGS + RA_REG_IDX(W)];
+    if (slot.base && slot.serial == RA_REG_SERIAL(W)) base = slot.base + RA_REG_OFF(W);
+  }
+  return base;
+}
+
 // ------------------------------------------------------------------ direct (all-pairs) schedules
 // All-reduce.  Piece j of every round is owned by rank j.  Three roles per channel:
 //   scatter : push my input of piece p into p's window (kind 0), for every peer p
 //   reduce  : fold my own piece with the n-1 arrivals in rank order, write it to recvbuff
 //             and push it into every peer's window (kind 1)
 //   gather  : copy the n-1 finished pieces that arrive (kind 1) into recvbuff
+// The workgroup serves nCtx channels (two for the scatter and gather workgroups of the two-rank role pairing, see
+// raCollKernel: channels ch0 and ch0 + 1 with LDS blocks sh0 and sh1), taking their rounds in turn, one step on each.
 template <typename T, int OP>
-__device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const RaWork& w, int role) {
-  const int n = uniformInt(cxs[0]->nRanks), r = uniformInt(cxs[0]->rank);
+__device__ __forceinline__ void directAllReduce(Ctx& cx, LdsChan* sh0, LdsChan* sh1, int ch0, int nCtx, const RaWork& w, int role) {
+  const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
   role = uniformInt(role); nCtx = uniformInt(nCtx);
   const Rounds R(w, n);
   const uint32_t peers = peersMask(n, r);
@@ -895,16 +1037,16 @@ __device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const Ra
   // and where its recvbuff is registered; a reducer that has that registration mapped writes its finished piece
   // straight into the peer's recvbuff and says so with its first broadcast-phase post, and the peer's gather role
   // then has nothing to copy for it.  The words travel beside the FIFO slots, once per launch and channel.
-  const bool words = !cxs[0]->comm->netMode;
-  if (role == 0 && cxs[0]->tid < n)
-    for (int c = 0; c < nCtx; c++) cxs[c]->sh->auxOut[cxs[c]->tid] = w.regWord;
-  // A workgroup that serves several channels (nCtx > 1: the scatter and gather roles with two ranks, see raCollKernel)
-  // takes their rounds in turn, one step on each.
+  const bool words = !cx.comm->netMode;
+  if (role == 0 && cx.tid < n) {
+    sh0->auxOut[cx.tid] = w.regWord;
+    if (nCtx > 1) sh1->auxOut[cx.tid] = w.regWord;
+  }
   const size_t stride = (size_t)uniformInt(w.nChannels);
-  for (size_t k = 0; (size_t)uniformInt(cxs[0]->ch) + k * stride < R.nRounds; k++)
+  for (size_t k = 0; (size_t)ch0 + k * stride < R.nRounds; k++)
    for (int c = 0; c < nCtx; c++) {
-    Ctx& cx = *cxs[c];
-    const size_t g = (size_t)uniformInt(cx.ch) + k * stride;
+    cx.select(c ? sh1 : sh0, ch0 + c);
+    const size_t g = (size_t)cx.ch + k * stride;
     if (g >= R.nRounds) continue;
     const bool first = k == 0;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
@@ -914,19 +1056,19 @@ __device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const Ra
         // all n-1 pieces in one fused pass when they have the same length and need no scaling
         RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
         size_t ne0 = 0; bool same = OP != RA_OP_PREMULSUM;
-        for (int i = 0; i < n - 1; i++) {
+        RC_EACH(i, 0, n - 1,
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
           size_t off, ne; R.piece(g, p, off, ne);
           if (i == 0) ne0 = ne; else same = same && ne == ne0;
-          pa.src[i] = (const char*)(in + off); pa.dst[i] = cx.sendSlot(p, 0);
-        }
+          pa.src[i] = uniformPtr((const char*)(in + off)); pa.dst[i] = cx.sendSlot(p, 0);
+        )
         if (same) { pairCopyWG<true>(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
-        for (int i = 0; i < n - 1; i++) {
+        for (int i = 0; i < n - 1; i++) {              // (a loop that indexes no argument array: one copy of the code)
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(p, 0);
-          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+          a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = cx.sendSlot(p, 0);
+          rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
         }
       });
     } else if (role == 1) {
@@ -936,12 +1078,7 @@ __device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const Ra
         if (first && words) {
           if (cx.tid < n && cx.tid != r) {
             const int p = cx.tid;
-            const uint64_t W = w.peerRegs ? cx.sh->auxIn[p] : 0;
-            uint64_t base = 0;
-            if ((W & RA_REG_VALID) && RA_REG_IDX(W) < RA_MAX_REGS) {
-              const RaRegSlot slot = cx.comm->regTable[p * RA_MAX_REGS + RA_REG_IDX(W)];
-              if (slot.base && slot.serial == RA_REG_SERIAL(W)) base = slot.base + RA_REG_OFF(W);
-            }
+            const uint64_t base = regBaseOf(cx.comm, p, w.peerRegs ? cx.sh->auxIn[p] : 0);
             cx.sh->directBase[p] = base;
             cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
           }
@@ -949,17 +1086,16 @@ __device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const Ra
         }
         size_t off, ne; R.piece(g, r, off, ne);
         RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
-        for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off); a.nLocal = 1;
-        int k = 1, nDirect = 0;
-        for (int i = 1; i < n; i++) {
+        RC_EACH(j, 0, n, a.src[j] = (j == r) ? uniformPtr((const char*)(in + off)) : cx.recvSlot(j, 0);)
+        a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+        int nDirect = 0;
+        RC_EACH(i, 1, n,
           const int p = (r + i) % n;
-          const uint64_t base = cx.sh->directBase[p];
-         
-          a.dst[k++] = base ? (char*)base + off * sizeof(T) : cx.sendSlot(p, 1);
+          const uint64_t base = uniform64(cx.sh->directBase[p]);
+          a.dst[i] = base ? (char*)base + off * sizeof(T) : cx.sendSlot(p, 1);
           nDirect += base != 0;
-        }
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        )
+        rcWG<T, OP, RC_FOLD_ALL>(a, ne, cx.tid, cx.nthr);
         if (cx.tid == 0) {
           if (nDirect) __hip_atomic_fetch_add(&cx.comm->stats[0], (uint64_t)nDirect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (n - 1 - nDirect) __hip_atomic_fetch_add(&cx.comm->stats[1], (uint64_t)(n - 1 - nDirect), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -969,71 +1105,66 @@ __device__ __noinline__ void directAllReduce(Ctx* const* cxs, int nCtx, const Ra
       cx.auxRecv = words && first && w.regWord != 0;
       cx.step(peers, 1, 0, 0, [&]() {
         // pieces a peer wrote straight into recvbuff need no copy
-        RcArgs pa; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
-        size_t ne0 = 0; bool same = true; int np = 0;
-        for (int i = 1; i < n; i++) {
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        size_t ne0 = 0; bool same = true; bool anyDirect = false;
+        RC_EACH(i, 1, n,
           const int p = (r + n - i) % n;
-          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
+          anyDirect = anyDirect || uniform64(cx.sh->auxIn[p]) == RA_AUX_DIRECT;
           size_t off, ne; R.piece(g, p, off, ne);
-          if (np == 0) ne0 = ne; else same = same && ne == ne0;
-          pa.src[np] = cx.recvSlot(p, 1); pa.dst[np] = (char*)(out + off); np++;
-        }
-        pa.ns = np; pa.nd = np;
-        if (np == 0) return;
-        if (same) { pairCopyWG<false>(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
+          if (i == 1) ne0 = ne; else same = same && ne == ne0;
+          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = uniformPtr((char*)(out + off));
+        )
+        if (same && !anyDirect) { pairCopyWG<false>(pa, ne0 * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
-          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
+          if (uniform64(cx.sh->auxIn[p]) == RA_AUX_DIRECT) continue;
           size_t off, ne; R.piece(g, p, off, ne);
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = (char*)(out + off); a.nLocal = 1;
-          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+          copyWG<CP_END>(a, ne * sizeof(T), cx.tid, cx.nthr);
         }
       });
     }
   }
-  for (int c = 0; c < nCtx; c++) { cxs[c]->auxRecv = 0; cxs[c]->auxSend = 0; }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers
 // elements [g*chunk, (g+1)*chunk) of every block.  Roles: scatter, reduce.
 template <typename T, int OP>
-__device__ __noinline__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
+__device__ __forceinline__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
   role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
-    const size_t off = g * w.chunkElems;
-    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+  const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
+  const size_t nRounds = (count + chunk - 1) / chunk;
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const size_t off = g * chunk;
+    const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
-        if (OP != RA_OP_PREMULSUM) {
-          RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
-          for (int i = 0; i < n - 1; i++) {
-            const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
-            pa.src[i] = (const char*)(in + (size_t)p * w.count + off); pa.dst[i] = cx.sendSlot(p, 0);
-          }
-          pairCopyWG<true>(pa, ne * sizeof(T), cx.tid, cx.nthr);
-          return;
-        }
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        RC_EACH(i, 0, n - 1,
+          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
+          pa.src[i] = uniformPtr((const char*)(in + (size_t)p * count + off)); pa.dst[i] = cx.sendSlot(p, 0);
+        )
+        if (OP != RA_OP_PREMULSUM) { pairCopyWG<true>(pa, ne * sizeof(T), cx.tid, cx.nthr); return; }
         for (int i = 0; i < n - 1; i++) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + (size_t)p * w.count + off); a.dst[0] = cx.sendSlot(p, 0);
-          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+          a.src[0] = uniformPtr((const char*)(in + (size_t)p * count + off)); a.dst[0] = cx.sendSlot(p, 0);
+          rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
         }
       });
     } else {
       cx.step(peers, 0, 0, 0, [&]() {
         RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
-        for (int j = 0; j < n; j++)
-          a.src[j] = (j == r) ? (const char*)(in + (size_t)r * w.count + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off); a.nLocal = 1;
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        RC_EACH(j, 0, n, a.src[j] = (j == r) ? uniformPtr((const char*)(in + (size_t)r * count + off)) : cx.recvSlot(j, 0);)
+        a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+        rcWG<T, OP, RC_FOLD_ONE>(a, ne, cx.tid, cx.nthr);
       });
     }
   }
@@ -1041,13 +1172,13 @@ __device__ __noinline__ void directReduceScatter(Ctx& cx, const RaWork& w, int r
 
 // All-gather (bytes): roles: spread (my block into every peer's window and into my own
 // recvbuff slot unless in place), gather.
-__device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
+__device__ __forceinline__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
   role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
-  const size_t nbytes = w.count * w.elemSize;          // per rank
-  const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
+  const size_t nbytes = uniform64(w.count * w.elemSize);          // per rank
+  const size_t chunkB = uniform64(w.chunkElems * w.elemSize);
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
   // Registered receive buffers (zero-copy all-gather).  A spreader may write into a peer's recvbuff only once that
   // peer's launch has begun, and it has to learn where the buffer is: for blocks of RA_AG_ANNOUNCE_BYTES and more
   // (a rule every rank evaluates alike) each gather workgroup first sends its registration word to every peer on the
@@ -1065,19 +1196,14 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
     cx.step(peers, 0, 0, 0, [&]() {
       if (cx.tid < n && cx.tid != r) {
         const int p = cx.tid;
-        const uint64_t W = w.peerRegs ? cx.sh->auxIn[p] : 0;
-        uint64_t base = 0;
-        if ((W & RA_REG_VALID) && RA_REG_IDX(W) < RA_MAX_REGS) {
-          const RaRegSlot slot = cx.comm->regTable[p * RA_MAX_REGS + RA_REG_IDX(W)];
-          if (slot.base && slot.serial == RA_REG_SERIAL(W)) base = slot.base + RA_REG_OFF(W);
-        }
+        const uint64_t base = regBaseOf(cx.comm, p, w.peerRegs ? cx.sh->auxIn[p] : 0);
         cx.sh->directBase[p] = base;
         cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
       }
     });
     cx.auxRecv = 0;
   }
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const bool first = g == (size_t)cx.ch;
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
@@ -1086,19 +1212,21 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
       cx.auxSend = announce && first;
       cx.step(0, 0, peers, 1, [&]() {
         RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = w.send + off;
-        int k = 0, nDirect = 0;
-        char* mine = w.recv + (size_t)r * nbytes + off;
-        if (mine != w.send + off) { a.dst[k++] = mine; a.nLocal = 1; }
-        for (int i = 1; i < n; i++) {
+        a.src[0] = uniformPtr(w.send + off);
+        char* mine = uniformPtr(w.recv + (size_t)r * nbytes + off);
+        const int lead = mine != a.src[0] ? 1 : 0;         // out of place: my own block goes to my recvbuff as well
+        int nDirect = 0;
+        // destination i (i = 1 .. n-1) is peer (r + i) % n; with the local copy in front they sit at dst[i], else at dst[i-1]
+        char* peerDst[RA_MAX_SRCS];
+        RC_EACH(i, 1, n,
           const int p = (r + i) % n;
-          const uint64_t base = cx.sh->directBase[p];
-         
-          a.dst[k++] = base ? (char*)base + (size_t)r * nbytes + off : cx.sendSlot(p, 1);
+          const uint64_t base = uniform64(cx.sh->directBase[p]);
+          peerDst[i] = base ? (char*)base + (size_t)r * nbytes + off : cx.sendSlot(p, 1);
           nDirect += base != 0;
-        }
-        a.nd = k;
-        copyWG(a, nb, cx.tid, cx.nthr);
+        )
+        if (lead) { a.dst[0] = mine; RC_EACH(i, 1, n, a.dst[i] = peerDst[i];) a.nd = n; a.nLocal = 1; }
+        else { RC_EACH(i, 1, n, a.dst[i - 1] = peerDst[i];) a.nd = n - 1; a.nLocal = 0; }
+        copyWG<CP_SPREAD>(a, nb, cx.tid, cx.nthr);
         if (announce && cx.tid == 0) {
           if (nDirect) __hip_atomic_fetch_add(&cx.comm->stats[0], (uint64_t)nDirect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (n - 1 - nDirect) __hip_atomic_fetch_add(&cx.comm->stats[1], (uint64_t)(n - 1 - nDirect), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1108,15 +1236,21 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
       cx.auxRecv = announce && first && w.regWord != 0;
       cx.step(peers, 1, 0, 0, [&]() {
         // blocks a peer wrote straight into recvbuff need no copy
-        RcArgs pa; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
-        int np = 0;
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+        bool anyDirect = false;
+        RC_EACH(i, 1, n,
+          const int p = (r + n - i) % n;
+          anyDirect = anyDirect || uniform64(cx.sh->auxIn[p]) == RA_AUX_DIRECT;
+          pa.src[i - 1] = cx.recvSlot(p, 1); pa.dst[i - 1] = uniformPtr(w.recv + (size_t)p * nbytes + off);
+        )
+        if (!anyDirect) { pairCopyWG<false>(pa, nb, cx.tid, cx.nthr); return; }
         for (int i = 1; i < n; i++) {
           const int p = (r + n - i) % n;
-          if (cx.sh->auxIn[p] == RA_AUX_DIRECT) continue;
-          pa.src[np] = cx.recvSlot(p, 1); pa.dst[np] = w.recv + (size_t)p * nbytes + off; np++;
+          if (uniform64(cx.sh->auxIn[p]) == RA_AUX_DIRECT) continue;
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0; a.nLocal = 1;
+          a.src[0] = cx.recvSlot(p, 1); a.dst[0] = uniformPtr(w.recv + (size_t)p * nbytes + off);
+          copyWG<CP_END>(a, nb, cx.tid, cx.nthr);
         }
-        pa.ns = np; pa.nd = np;
-        if (np) pairCopyWG<false>(pa, nb, cx.tid, cx.nthr);
       });
     }
   }
@@ -1126,33 +1260,36 @@ __device__ void directAllGather(Ctx& cx, const RaWork& w, int role) {
 // Broadcast (bytes): the root spreads each chunk into every peer's window (and into its own recvbuff
 // when out of place); every other rank copies what arrives from the root.  Role of
 // src/device/broadcast.h on the all-pairs links: one hop from the root to everybody.
-__device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
+__device__ __forceinline__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank), root = uniformInt(w.root);
   role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
-  const size_t nbytes = w.count * w.elemSize;
-  const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
+  const size_t nbytes = uniform64(w.count * w.elemSize);
+  const size_t chunkB = uniform64(w.chunkElems * w.elemSize);
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
   if ((role == 0) != (r == root)) return;
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     cx.stepBytes = (uint32_t)nb;
     if (role == 0) {
       cx.step(0, 0, peers, 1, [&]() {
         RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = w.send + off;
-        int k = 0;
-        if (w.recv != w.send) { a.dst[k++] = w.recv + off; a.nLocal = 1; }
-        for (int i = 1; i < n; i++) { const int p = (r + i) % n; a.dst[k++] = cx.sendSlot(p, 1); }
-        a.nd = k;
-        copyWG(a, nb, cx.tid, cx.nthr);
+        a.src[0] = uniformPtr(w.send + off);
+        if (w.recv != w.send) {
+          a.dst[0] = uniformPtr(w.recv + off); a.nLocal = 1; a.nd = n;
+          RC_EACH(i, 1, n, a.dst[i] = cx.sendSlot((r + i) % n, 1);)
+        } else {
+          a.nLocal = 0; a.nd = n - 1;
+          RC_EACH(i, 1, n, a.dst[i - 1] = cx.sendSlot((r + i) % n, 1);)
+        }
+        copyWG<CP_SPREAD>(a, nb, cx.tid, cx.nthr);
       });
     } else {
       cx.step(1u << root, 1, 0, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = cx.recvSlot(root, 1); a.dst[0] = w.recv + off; a.nLocal = 1;
-        copyWG(a, nb, cx.tid, cx.nthr);
+        a.src[0] = cx.recvSlot(root, 1); a.dst[0] = uniformPtr(w.recv + off); a.nLocal = 1;
+        copyWG<CP_END>(a, nb, cx.tid, cx.nthr);
       });
     }
   }
@@ -1161,30 +1298,31 @@ __device__ void directBroadcast(Ctx& cx, const RaWork& w, int role) {
 // Reduce to a root: every other rank pushes its input into the root's window; the root folds the n
 // contributions in rank order (role of src/device/reduce.h, one hop).
 template <typename T, int OP>
-__device__ __noinline__ void directReduce(Ctx& cx, const RaWork& w, int role) {
+__device__ __forceinline__ void directReduce(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank), root = uniformInt(w.root);
   role = uniformInt(role);
   const uint32_t peers = peersMask(n, r);
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
+  const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
+  const size_t nRounds = (count + chunk - 1) / chunk;
   if ((role == 1) != (r == root)) return;
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
-    const size_t off = g * w.chunkElems;
-    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const size_t off = g * chunk;
+    const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       cx.step(0, 0, 1u << root, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-        a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(root, 0);
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = cx.sendSlot(root, 0);
+        rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
       });
     } else {
       cx.step(peers, 0, 0, 0, [&]() {
         RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
-        for (int j = 0; j < n; j++) a.src[j] = (j == r) ? (const char*)(in + off) : cx.recvSlot(j, 0);
-        a.dst[0] = (char*)(out + off); a.nLocal = 1;
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        RC_EACH(j, 0, n, a.src[j] = (j == r) ? uniformPtr((const char*)(in + off)) : cx.recvSlot(j, 0);)
+        a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+        rcWG<T, OP, RC_FOLD_ONE>(a, ne, cx.tid, cx.nthr);
       });
     }
   }
@@ -1197,7 +1335,7 @@ __device__ __noinline__ void directReduce(Ctx& cx, const RaWork& w, int role) {
 struct RingPos {
   int ix, prev, next;
   const int8_t* order;
-  __device__ RingPos(const Ctx& cx) {
+  __device__ __forceinline__ RingPos(const Ctx& cx) {
     order = cx.comm->ringRanks[cx.ch % cx.comm->nRings];
     ix = 0;
     for (int i = 0; i < cx.nRanks; i++) if (order[i] == cx.rank) ix = i;
@@ -1208,40 +1346,40 @@ struct RingPos {
 };
 
 template <typename T, int OP>
-__device__ __noinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
+__device__ __forceinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
   const int n = uniformInt(cx.nRanks);
   const Rounds R(w, n);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  for (size_t g = uniformInt(cx.ch); g < R.nRounds; g += (size_t)uniformInt(w.nChannels)) {
+  for (size_t g = cx.ch; g < R.nRounds; g += (size_t)uniformInt(w.nChannels)) {
     size_t off, ne;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
     // step 0: seed the piece behind me
     R.piece(g, (rp.ix + n - 1) % n, off, ne);
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(rp.next, 0);
-      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: local + received -> next
     for (int j = 2; j < n; j++) {
       R.piece(g, (rp.ix + n - j) % n, off, ne);
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-        a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+        a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(rp.prev, 0);
         a.dst[0] = cx.sendSlot(rp.next, 0);
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        rcWG<T, OP, RC_HOP>(a, ne, cx.tid, cx.nthr);
       });
     }
     // my own piece: final value, kept and sent on
     R.piece(g, rp.ix, off, ne);
     cx.step(pm, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
-      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(rp.prev, 0);
+      a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP, RC_HOP_KEEP>(a, ne, cx.tid, cx.nthr);
     });
     // n-2 hops: keep and forward finished pieces
     for (int j = 1; j < n - 1; j++) {
@@ -1249,16 +1387,16 @@ __device__ __noinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
-        copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+        a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
+        copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
       });
     }
     // last finished piece
     R.piece(g, (rp.ix + 1) % n, off, ne);
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = (char*)(out + off); a.nLocal = 1;
-      copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+      copyWG<CP_END>(a, ne * sizeof(T), cx.tid, cx.nthr);
     });
   }
 }
@@ -1266,77 +1404,76 @@ __device__ __noinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
 // Ring reduce-scatter (src/device/reduce_scatter.h:36-57): blocks travel in the order
 // order[n-1], ..., order[0] relative to each rank's rotated ring and finish at their owner.
 template <typename T, int OP>
-__device__ __noinline__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
+__device__ __forceinline__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
   const int n = uniformInt(cx.nRanks);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
-    const size_t off = g * w.chunkElems;
-    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+  const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
+  const size_t nRounds = (count + chunk - 1) / chunk;
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const size_t off = g * chunk;
+    const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
-    int blk = rp.order[(rp.ix + n - 1) % n];
+    int blk = uniformInt(rp.order[(rp.ix + n - 1) % n]);
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.dst[0] = cx.sendSlot(rp.next, 0);
-      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      a.src[0] = uniformPtr((const char*)(in + (size_t)blk * count + off)); a.dst[0] = cx.sendSlot(rp.next, 0);
+      rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
     });
     for (int j = 2; j < n; j++) {
-      blk = rp.order[(rp.ix + n - j) % n];
+      blk = uniformInt(rp.order[(rp.ix + n - j) % n]);
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-        a.src[0] = (const char*)(in + (size_t)blk * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
+        a.src[0] = uniformPtr((const char*)(in + (size_t)blk * count + off)); a.src[1] = cx.recvSlot(rp.prev, 0);
         a.dst[0] = cx.sendSlot(rp.next, 0);
-        rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+        rcWG<T, OP, RC_HOP>(a, ne, cx.tid, cx.nthr);
       });
     }
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
-      a.src[0] = (const char*)(in + (size_t)cx.rank * w.count + off); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = (char*)(out + off); a.nLocal = 1;
-      rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+      a.src[0] = uniformPtr((const char*)(in + (size_t)cx.rank * count + off)); a.src[1] = cx.recvSlot(rp.prev, 0);
+      a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+      rcWG<T, OP, RC_HOP_END>(a, ne, cx.tid, cx.nthr);
     });
   }
 }
 
 // Ring all-gather (src/device/all_gather.h:69-145), bytes.
-__device__ void ringAllGather(Ctx& cx, const RaWork& w) {
+__device__ __forceinline__ void ringAllGather(Ctx& cx, const RaWork& w) {
   const int n = uniformInt(cx.nRanks);
   const RingPos rp(cx);
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
-  const size_t nbytes = w.count * w.elemSize;
-  const size_t chunkB = w.chunkElems * w.elemSize;
-  const size_t nRounds = uniform64((nbytes + chunkB - 1) / chunkB);
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+  const size_t nbytes = uniform64(w.count * w.elemSize);
+  const size_t chunkB = uniform64(w.chunkElems * w.elemSize);
+  const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     cx.stepBytes = (uint32_t)nb;
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-      a.src[0] = w.send + off;
-      int k = 0;
-      char* mine = w.recv + (size_t)cx.rank * nbytes + off;
-      if (mine != w.send + off) { a.dst[k++] = mine; a.nLocal = 1; }
-      a.dst[k++] = cx.sendSlot(rp.next, 0);
-      a.nd = k;
-      copyWG(a, nb, cx.tid, cx.nthr);
+      a.src[0] = uniformPtr(w.send + off);
+      char* mine = uniformPtr(w.recv + (size_t)cx.rank * nbytes + off);
+      if (mine != a.src[0]) { a.dst[0] = mine; a.dst[1] = cx.sendSlot(rp.next, 0); a.nd = 2; a.nLocal = 1; }
+      else { a.dst[0] = cx.sendSlot(rp.next, 0); a.nd = 1; a.nLocal = 0; }
+      copyWG<CP_SPREAD>(a, nb, cx.tid, cx.nthr);
     });
     for (int j = 1; j < n - 1; j++) {
-      const int blk = rp.order[(rp.ix + n - j) % n];
+      const int blk = uniformInt(rp.order[(rp.ix + n - j) % n]);
       cx.step(pm, 0, nm, 0, [&]() {
         RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
         a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
-        copyWG(a, nb, cx.tid, cx.nthr);
+        a.dst[0] = uniformPtr(w.recv + (size_t)blk * nbytes + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
+        copyWG<CP_FWD>(a, nb, cx.tid, cx.nthr);
       });
     }
-    const int blk = rp.order[(rp.ix + 1) % n];
+    const int blk = uniformInt(rp.order[(rp.ix + 1) % n]);
     cx.step(pm, 0, 0, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = w.recv + (size_t)blk * nbytes + off; a.nLocal = 1;
-      copyWG(a, nb, cx.tid, cx.nthr);
+      a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = uniformPtr(w.recv + (size_t)blk * nbytes + off); a.nLocal = 1;
+      copyWG<CP_END>(a, nb, cx.tid, cx.nthr);
     });
   }
 }
@@ -1349,7 +1486,7 @@ __device__ void ringAllGather(Ctx& cx, const RaWork& w) {
 // and down pipelines overlap: role 0 runs the up steps (the root's up step also starts the
 // way down), role 1 runs the down steps.  Round g covers elements [g*chunk, (g+1)*chunk).
 template <typename T, int OP>
-__device__ __noinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
+__device__ __forceinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks);
   role = uniformInt(role);
   const RingPos rp(cx);
@@ -1357,31 +1494,32 @@ __device__ __noinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) 
   const int parent = rp.prev, child = rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
-  const size_t nRounds = uniform64((w.count + w.chunkElems - 1) / w.chunkElems);
-  for (size_t g = uniformInt(cx.ch); g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
-    const size_t off = g * w.chunkElems;
-    const size_t ne = w.count - off < w.chunkElems ? w.count - off : w.chunkElems;
+  const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
+  const size_t nRounds = (count + chunk - 1) / chunk;
+  for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const size_t off = g * chunk;
+    const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       if (leaf) {
         cx.step(0, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.dst[0] = cx.sendSlot(parent, 0);
-          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+          a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = cx.sendSlot(parent, 0);
+          rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
         });
       } else if (!root) {
         cx.step(1u << child, 0, 1u << parent, 0, [&]() {
           RcArgs a; a.ns = 2; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
+          a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(child, 0);
           a.dst[0] = cx.sendSlot(parent, 0);
-          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+          rcWG<T, OP, RC_HOP>(a, ne, cx.tid, cx.nthr);
         });
       } else {
         cx.step(1u << child, 0, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
-          a.src[0] = (const char*)(in + off); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
-          rcWG<T, OP>(a, ne, cx.tid, cx.nthr);
+          a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(child, 0);
+          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
+          rcWG<T, OP, RC_HOP_KEEP>(a, ne, cx.tid, cx.nthr);
         });
       }
     } else {
@@ -1389,15 +1527,15 @@ __device__ __noinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int role) 
       if (leaf) {
         cx.step(1u << parent, 1, 0, 0, [&]() {
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = (char*)(out + off); a.nLocal = 1;
-          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+          a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+          copyWG<CP_END>(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       } else {
         cx.step(1u << parent, 1, 1u << child, 1, [&]() {
           RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
           a.src[0] = cx.recvSlot(parent, 1);
-          a.dst[0] = (char*)(out + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
-          copyWG(a, ne * sizeof(T), cx.tid, cx.nthr);
+          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
+          copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       }
     }
@@ -1857,19 +1995,20 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raNoAllocAllReduceKernel(RaNaAr
 // finished slices into recvbuff.  A buffer of the window region holds n slots of one piece for the first exchange and
 // n for the second.  In place: a slice of recvbuff is written only by the workgroup that has already read it.
 template <typename T, int OP>
-__device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uint64_t epoch, int* aborted) {
-  const int n = comm->nRanks, r = comm->rank, tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+__device__ __forceinline__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uint64_t epoch, LdsInt* aborted) {
+  const int n = uniformInt(comm->nRanks), r = uniformInt(comm->rank), tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
   const int buf = (int)(epoch & 1u);
   constexpr size_t ROW = 64 * (16 / sizeof(T));                      // elements of a 1 KiB row
-  const size_t pe = ((w.count + n - 1) / n + ROW - 1) / ROW * ROW;   // elements of a piece
+  const size_t count = uniform64(w.count);
+  const size_t pe = ((count + n - 1) / n + ROW - 1) / ROW * ROW;   // elements of a piece
   const size_t se = ((pe + gridDim.x - 1) / gridDim.x + ROW - 1) / ROW * ROW;   // ... of it one workgroup handles
   const size_t s0 = (size_t)b * se;
   if (s0 >= pe) return;                                               // the same on every rank: no flags either
   const size_t s1 = s0 + se < pe ? s0 + se : pe;
   auto slice = [&](int j, size_t& off, size_t& ne) {                  // my slice of piece j, clipped to the payload
     const size_t lo = (size_t)j * pe + s0, hi = (size_t)j * pe + s1;
-    off = lo < w.count ? lo : w.count;
-    ne = lo < w.count ? (hi < w.count ? hi : w.count) - lo : 0;
+    off = lo < count ? lo : count;
+    ne = lo < count ? (hi < count ? hi : count) - lo : 0;
   };
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
@@ -1879,12 +2018,12 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
   {
     RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
     size_t ne0 = 0; bool same = OP != RA_OP_PREMULSUM;
-    for (int i = 0; i < n - 1; i++) {
+    RC_EACH(i, 0, n - 1,
       const int p = (r + 1 + (i + b) % (n - 1)) % n;                  // workgroups start on different links
       size_t off, ne; slice(p, off, ne);
       if (i == 0) ne0 = ne; else same = same && ne == ne0;
-      pa.src[i] = (const char*)(in + off); pa.dst[i] = comm->win[p] + area1 + (size_t)r * peB + sB;
-    }
+      pa.src[i] = uniformPtr((const char*)(in + off)); pa.dst[i] = uniformPtr(comm->win[p] + area1 + (size_t)r * peB + sB);
+    )
     if (same) {
       pairCopyWG<true>(pa, ne0 * sizeof(T), tid, nthr);
     } else {
@@ -1892,8 +2031,8 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
         const int p = (r + 1 + (i + b) % (n - 1)) % n;
         size_t off, ne; slice(p, off, ne);
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
-        a.src[0] = pa.src[i]; a.dst[0] = pa.dst[i];
-        rcWG<T, OP>(a, ne, tid, nthr);
+        a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = uniformPtr(comm->win[p] + area1 + (size_t)r * peB + sB);
+        rcWG<T, OP, RC_SEND>(a, ne, tid, nthr);
       }
     }
   }
@@ -1907,13 +2046,13 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
   }
   if (tid < 64) drainVmem();
   __syncthreads();
-  if (!*aborted) {
+  if (!uniformInt(*aborted)) {
     size_t off, ne; slice(r, off, ne);
     RcArgs a; a.ns = n; a.nd = n; a.preIdx = r; a.post = true; a.opArg = w.opArg;
-    for (int j = 0; j < n; j++) a.src[j] = j == r ? (const char*)(in + off) : comm->win[r] + area1 + (size_t)j * peB + sB;
-    a.dst[0] = (char*)(out + off); a.nLocal = 1;
-    for (int i = 1; i < n; i++) a.dst[i] = comm->win[(r + i) % n] + area2 + (size_t)r * peB + sB;
-    rcWG<T, OP>(a, ne, tid, nthr);
+    RC_EACH(j, 0, n, a.src[j] = j == r ? uniformPtr((const char*)(in + off)) : uniformPtr((const char*)comm->win[r] + area1 + (size_t)j * peB + sB);)
+    a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+    RC_EACH(i, 1, n, a.dst[i] = uniformPtr(comm->win[(r + i) % n] + area2 + (size_t)r * peB + sB);)
+    rcWG<T, OP, RC_FOLD_ALL>(a, ne, tid, nthr);
   }
   drainVmem();
   __syncthreads();
@@ -1925,15 +2064,15 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
   }
   if (tid < 64) drainVmem();
   __syncthreads();
-  if (!*aborted) {
+  if (!uniformInt(*aborted)) {
     RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0; pa.nLocal = n - 1;
     size_t ne0 = 0; bool same = true;
-    for (int i = 0; i < n - 1; i++) {
+    RC_EACH(i, 0, n - 1,
       const int p = (r + n - 1 - i) % n;
       size_t off, ne; slice(p, off, ne);
       if (i == 0) ne0 = ne; else same = same && ne == ne0;
-      pa.src[i] = comm->win[r] + area2 + (size_t)p * peB + sB; pa.dst[i] = (char*)(out + off);
-    }
+      pa.src[i] = uniformPtr((const char*)comm->win[r] + area2 + (size_t)p * peB + sB); pa.dst[i] = uniformPtr((char*)(out + off));
+    )
     if (same) {
       pairCopyWG<false>(pa, ne0 * sizeof(T), tid, nthr);
     } else {
@@ -1941,11 +2080,24 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
         const int p = (r + n - 1 - i) % n;
         size_t off, ne; slice(p, off, ne);
         RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0; a.nLocal = 1;
-        a.src[0] = pa.src[i]; a.dst[0] = pa.dst[i];
-        copyWG(a, ne * sizeof(T), tid, nthr);
+        a.src[0] = uniformPtr((const char*)comm->win[r] + area2 + (size_t)p * peB + sB); a.dst[0] = uniformPtr((char*)(out + off));
+        copyWG<CP_END>(a, ne * sizeof(T), tid, nthr);
       }
     }
   }
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(1024) void raTwoExchangeKernel(const RaDevComm* __restrict__ comm, RaWork w) {
+  __shared__ int aborted;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
+  const uint64_t epoch = comm->osEpoch[b] + 1;
+  if (tid == 0) aborted = 0;
+  __syncthreads();
+  twoExchangeAllReduce<T, OP>(comm, w, epoch, (LdsInt*)&aborted);
+  __syncthreads();
+  if (tid == 0) comm->osEpoch[b] = epoch;
 }
 
 // ------------------------------------------------------------------ all-reduce in one exchange (mid-size payloads)
@@ -1957,24 +2109,20 @@ __device__ void twoExchangeAllReduce(const RaDevComm* comm, const RaWork& w, uin
 // peer because finishing a launch needs that peer's flags of the launch (the flow control of the low-latency kernel).
 // Every workgroup counts every launch (with or without work), so all of them agree on the parity.
 // In place: a slice is overwritten by the workgroup that pushed it, after its push.
+// Reduce-scatter (rank p is sent block p of sendbuff only; count is per rank) and all-gather (no fold: every sender's
+// slice is copied to its block of recvbuff; launched with T = int8 and a byte count) use the same exchange, with the
+// same link bytes as their FIFO schedules, so they take it at every size the window region has room for.
 template <typename T, int OP>
 __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restrict__ comm, RaWork w) {
-  __shared__ int aborted;
-  RcArgs rc;
-  const int n = comm->nRanks, r = comm->rank, tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
+  __shared__ int abortedVar;
+  LdsInt* aborted = (LdsInt*)&abortedVar;
+  const int n = uniformInt(comm->nRanks), r = uniformInt(comm->rank), tid = threadIdx.x, nthr = blockDim.x, b = blockIdx.x;
   if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
   const uint64_t epoch = comm->osEpoch[b] + 1;
-  if (w.oneShot == 2) {                              // all-reduce in two exchanges
-    if (tid == 0) aborted = 0;
-    __syncthreads();
-    twoExchangeAllReduce<T, OP>(comm, w, epoch, &aborted);
-    __syncthreads();
-    if (tid == 0) comm->osEpoch[b] = epoch;
-    return;
-  }
   const int buf = (int)(epoch & 1u);
   constexpr size_t EPP = 16 / sizeof(T);
-  const size_t npacks = w.count / EPP;
+  const size_t count = uniform64(w.count);
+  const size_t npacks = count / EPP;
   size_t per = (npacks + gridDim.x - 1) / gridDim.x;
   per = (per + 63) / 64 * 64;                      // whole 1 KiB rows
   if (per == 0) per = 64;
@@ -1983,36 +2131,38 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
   if ((size_t)b <= last) {
     const size_t p0 = (size_t)b * per, p1 = p0 + per < npacks ? p0 + per : npacks;
     e0 = p0 * EPP;
-    ne = ((size_t)b == last ? w.count : p1 * EPP) - e0;
+    ne = ((size_t)b == last ? count : p1 * EPP) - e0;
   }
-  // Reduce-scatter (rank p is sent block p of sendbuff only; count is per rank) and all-gather (no fold: every sender's
-  // slice is copied to its block of recvbuff; launched with T = int8 and a byte count) use the same exchange, with the
-  // same link bytes as their FIFO schedules, so they take it at every size the window region has room for.
   const bool scatter = w.coll == RA_COLL_REDUCESCATTER, gather = w.coll == RA_COLL_ALLGATHER;
   const T* in = (const T*)w.send + e0;
   T* out = (T*)w.recv + e0;
   const size_t boff = e0 * sizeof(T);
-  if (tid == 0) aborted = 0;
+  if (tid == 0) *aborted = 0;
   if (ne) {
-    // 1. my slice to everyone
-    rc.ns = 1; rc.nd = n - 1; rc.preIdx = 0; rc.post = false; rc.nLocal = 0; rc.opArg = w.opArg;
-    rc.src[0] = (const char*)in;
-    for (int i = 0; i < n - 1; i++) {
-      const int p = (r + 1 + (i + b) % (n - 1)) % n;            // workgroups start on different links
-      rc.dst[i] = comm->win[p] + raOsDataOffset(comm->lay, buf, r) + boff;
-      if (scatter) rc.src[i] = (const char*)(in + (size_t)p * w.count);
-    }
+    // 1. my slice to everyone: entry i is peer (r + 1 + (i + b) % (n - 1)) % n, so that workgroups start on different links
+    RcArgs rc; rc.ns = 1; rc.nd = n - 1; rc.preIdx = 0; rc.post = false; rc.nLocal = 0; rc.opArg = w.opArg;
+    rc.src[0] = uniformPtr((const char*)in);
+    RC_EACH(i, 0, n - 1,
+      const int p = (r + 1 + (i + b) % (n - 1)) % n;
+      rc.dst[i] = uniformPtr(comm->win[p] + raOsDataOffset(comm->lay, buf, r) + boff);
+      if (scatter) rc.src[i] = uniformPtr((const char*)(in + (size_t)p * count));
+    )
     __syncthreads();                               // `aborted` is initialised
     if (scatter && OP != RA_OP_PREMULSUM) {
       rc.ns = n - 1;                               // n-1 independent copies, block p to rank p
       pairCopyWG<true>(rc, ne * sizeof(T), tid, nthr);
     } else if (scatter) {
-      RcArgs one; one.ns = 1; one.nd = 1; one.preIdx = 0; one.post = false; one.nLocal = 0; one.opArg = w.opArg;
-      for (int i = 0; i < n - 1; i++) { one.src[0] = rc.src[i]; one.dst[0] = rc.dst[i]; rcWG<T, OP>(one, ne, tid, nthr); }
+      for (int i = 0; i < n - 1; i++) {
+        const int p = (r + 1 + (i + b) % (n - 1)) % n;
+        RcArgs one; one.ns = 1; one.nd = 1; one.preIdx = 0; one.post = false; one.nLocal = 0; one.opArg = w.opArg;
+        one.src[0] = uniformPtr((const char*)(in + (size_t)p * count));
+        one.dst[0] = uniformPtr(comm->win[p] + raOsDataOffset(comm->lay, buf, r) + boff);
+        rcWG<T, OP, RC_SEND>(one, ne, tid, nthr);
+      }
     } else if (OP == RA_OP_PREMULSUM) {
-      rcWG<T, OP>(rc, ne, tid, nthr);
+      rcWG<T, OP, RC_SEND>(rc, ne, tid, nthr);     // (one source into n - 1 windows: the plain loop, or 1 -> 1 with two ranks)
     } else {
-      copyWG(rc, ne * sizeof(T), tid, nthr);
+      copyWG<CP_SPREAD>(rc, ne * sizeof(T), tid, nthr);
     }
     drainVmem();                                   // every wave: its stores are at their destination
     __syncthreads();
@@ -2021,80 +2171,81 @@ __global__ __launch_bounds__(1024) void raOneShotKernel(const RaDevComm* __restr
     if (tid < n && tid != r) stFlag((uint64_t*)(comm->win[tid] + raOsFlagOffset(comm->lay, buf, b, r)), 2 * epoch - 1);
     // 2. the peers' slices
     if (tid < n && tid != r) {
-      raSpin(comm, &aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), 2 * epoch - 1);
+      raSpin(comm, aborted, (const uint64_t*)(comm->win[r] + raOsFlagOffset(comm->lay, buf, b, tid)), 2 * epoch - 1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    if (gather) {
-      // every sender's slice to its block of recvbuff (my own from sendbuff, unless it is already there)
-      int np = 0;
-      for (int j = 0; j < n; j++) {
-        char* dst = (char*)out + (size_t)j * w.count * sizeof(T);
-        const char* src = j == r ? (const char*)in : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
-        if (j == r && src == dst) continue;
-        rc.src[np] = src; rc.dst[np] = dst; np++;
-      }
-      rc.ns = np; rc.nd = np; rc.preIdx = -1; rc.post = false; rc.nLocal = np;
-    } else {
-      rc.ns = n; rc.nd = 1; rc.preIdx = r; rc.post = true; rc.nLocal = 1;
-      for (int j = 0; j < n; j++)
-        rc.src[j] = j == r ? (const char*)(scatter ? in + (size_t)r * w.count : in) : comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff;
-      rc.dst[0] = (char*)out;
     }
     if (tid < 64) drainVmem();
     __syncthreads();
     // 3. the fold, in rank order (all-gather: the copies)
-    if (!aborted) {
-      if (gather) pairCopyWG<false>(rc, ne * sizeof(T), tid, nthr);
-      else rcWG<T, OP>(rc, ne, tid, nthr);
+    if (!uniformInt(*aborted)) {
+      if (gather) {
+        // every peer's slice to its block of recvbuff, then my own from sendbuff unless it is already there
+        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.nLocal = n - 1; pa.opArg = 0;
+        RC_EACH(i, 0, n - 1,
+          const int p = (r + 1 + i) % n;
+          pa.src[i] = uniformPtr((const char*)comm->win[r] + raOsDataOffset(comm->lay, buf, p) + boff);
+          pa.dst[i] = uniformPtr((char*)out + (size_t)p * count * sizeof(T));
+        )
+        pairCopyWG<false>(pa, ne * sizeof(T), tid, nthr);
+        char* mine = uniformPtr((char*)out + (size_t)r * count * sizeof(T));
+        if (mine != (const char*)in) {
+          RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.nLocal = 1; a.opArg = 0;
+          a.src[0] = uniformPtr((const char*)in); a.dst[0] = mine;
+          copyWG<CP_END>(a, ne * sizeof(T), tid, nthr);
+        }
+      } else {
+        RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.nLocal = 1; a.opArg = w.opArg;
+        RC_EACH(j, 0, n,
+          a.src[j] = j == r ? uniformPtr((const char*)(scatter ? in + (size_t)r * count : in))
+                            : uniformPtr((const char*)comm->win[r] + raOsDataOffset(comm->lay, buf, j) + boff);
+        )
+        a.dst[0] = uniformPtr((char*)out);
+        rcWG<T, OP, RC_FOLD_ONE>(a, ne, tid, nthr);
+      }
     }
   }
   __syncthreads();
   if (tid == 0) comm->osEpoch[b] = epoch;
 }
 
-// ------------------------------------------------------------------ the collective kernel
+// ------------------------------------------------------------------ the collective kernels
+// One kernel per schedule, everything inlined into it: no calls, no stack frame.
 // grid = roles * nChannels workgroups: blockIdx.x = role * nChannels + channel.  Exception (w.pairRoles, the all-pairs
 // all-reduce with two ranks): there a reducer moves twice the bytes of a scatter or gather step (two sources and two
 // destinations against one pair), so a scatter or gather workgroup serves TWO channels and all workgroups stay equally
 // busy: nChannels/2 scatter workgroups, nChannels reducers, nChannels/2 gather workgroups.
-template <typename T, int OP>
+enum { RA_K_DIRECT_ALLREDUCE, RA_K_DIRECT_REDUCESCATTER, RA_K_DIRECT_REDUCE, RA_K_RING_ALLREDUCE, RA_K_RING_REDUCESCATTER,
+       RA_K_CHAIN_ALLREDUCE };
+template <typename T, int OP, int K>
 __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict__ comm, RaWork w) {
-  __shared__ ChanShared sh, shB;
+  __shared__ ChanShared shA, shB;
+  LdsChan* const sh = RA_LDS_CHAN(shA);
   if (OP == RA_OP_PREMULSUM && w.opArgPtr) w.opArg = loadScalarArg<T>(w.opArgPtr);
-  if (w.pairRoles) {
-    // all-pairs all-reduce, two ranks
-    const int half = w.nChannels / 2, b = (int)blockIdx.x;
-    Ctx cx;
-    if (b >= half && b < half + w.nChannels) {
-      cx.init(comm, &sh, b - half, w.stepBytes);
-      Ctx* one[1] = {&cx};
-      directAllReduce<T, OP>(one, 1, w, 1);
-      cx.finish(1);
-    } else {
-      const int role = b < half ? 0 : 2;
-      const int ch0 = 2 * (b < half ? b : b - half - w.nChannels);
-      Ctx cxB;
-      cx.init(comm, &sh, ch0, w.stepBytes);
-      cxB.init(comm, &shB, ch0 + 1, w.stepBytes);
-      Ctx* two[2] = {&cx, &cxB};
-      directAllReduce<T, OP>(two, 2, w, role);
-      cx.finish(role);
-      cxB.finish(role);
+  Ctx cx;
+  if constexpr (K == RA_K_DIRECT_ALLREDUCE) {
+    LdsChan* const sh1 = RA_LDS_CHAN(shB);
+    int role = blockIdx.x / w.nChannels, ch0 = blockIdx.x % w.nChannels, nCtx = 1;
+    if (w.pairRoles) {
+      // all-pairs all-reduce, two ranks
+      const int half = w.nChannels / 2, b = (int)blockIdx.x;
+      if (b >= half && b < half + w.nChannels) { role = 1; ch0 = b - half; }
+      else { role = b < half ? 0 : 2; ch0 = 2 * (b < half ? b : b - half - w.nChannels); nCtx = 2; }
     }
+    role = uniformInt(role); ch0 = uniformInt(ch0); nCtx = uniformInt(nCtx);
+    if (nCtx == 2) Ctx::loadChannel(comm, sh1, ch0 + 1);
+    cx.init(comm, sh, ch0, w.stepBytes);
+    directAllReduce<T, OP>(cx, sh, sh1, ch0, nCtx, w, role);
+    __syncthreads();
+    Ctx::storeChannel(comm, sh, ch0, role);
+    if (nCtx == 2) Ctx::storeChannel(comm, sh1, ch0 + 1, role);
     return;
   }
-  Ctx cx;
-  const int role = blockIdx.x / w.nChannels;
-  cx.init(comm, &sh, blockIdx.x % w.nChannels, w.stepBytes);
-  if (w.algo == RA_ALGO_DIRECT) {
-    if (w.coll == RA_COLL_ALLREDUCE) { Ctx* one[1] = {&cx}; directAllReduce<T, OP>(one, 1, w, role); }
-    else if (w.coll == RA_COLL_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);
-    else if (w.coll == RA_COLL_REDUCE) directReduce<T, OP>(cx, w, role);
-  } else if (w.algo == RA_ALGO_RING) {
-    if (w.coll == RA_COLL_ALLREDUCE) ringAllReduce<T, OP>(cx, w);
-    else if (w.coll == RA_COLL_REDUCESCATTER) ringReduceScatter<T, OP>(cx, w);
-  } else {
-    if (w.coll == RA_COLL_ALLREDUCE) chainAllReduce<T, OP>(cx, w, role);
-  }
+  const int role = blockIdx.x / w.nChannels, ch = blockIdx.x % w.nChannels;
+  cx.init(comm, sh, ch, w.stepBytes);
+  if constexpr (K == RA_K_DIRECT_REDUCESCATTER) directReduceScatter<T, OP>(cx, w, role);
+  else if constexpr (K == RA_K_DIRECT_REDUCE) directReduce<T, OP>(cx, w, role);
+  else if constexpr (K == RA_K_RING_ALLREDUCE) ringAllReduce<T, OP>(cx, w);
+  else if constexpr (K == RA_K_RING_REDUCESCATTER) ringReduceScatter<T, OP>(cx, w);
+  else chainAllReduce<T, OP>(cx, w, role);
   cx.finish(role);
 }
