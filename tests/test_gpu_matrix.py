@@ -24,8 +24,11 @@ _spec.loader.exec_module(sweep)
 def test_every_instantiation_through_every_schedule(ranks, nbytes):
     import torch
     bed = TestBed(ranks, devices=tuple(range(torch.cuda.device_count())), env={"RCCL_AMD_SPIN_TIMEOUT_MS": "5000"})
+    # the case under way goes to a file as it starts: a run that takes the process down still names its case
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    trace = sweep.tracer_to(os.path.join(out, f"matrix_trace_{ranks}.log")) if os.path.isdir(out) and os.access(out, os.W_OK) else None
     try:
-        failures = sweep.run(bed, nbytes)
+        failures = sweep.run(bed, nbytes, trace=trace)
     finally:
         bed.close()
     assert not failures, failures[:5]

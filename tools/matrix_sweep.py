@@ -71,9 +71,10 @@ def one(bed, coll, dt, op, nbytes, in_place=False, pad=None):
     return [ex.check(dt, outs[root], orc.device_fold(dt, op, ins))], bed.plan(coll, count, dt)
 
 
-def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None, in_place=False, pad_elems=0):
+def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None, in_place=False, pad_elems=0, trace=None):
     """Walks the matrix on `bed`; returns the list of failures (strings).  Stops at the first rank that fails (a
-    timeout or a fault): nothing more is started on the GPU after that."""
+    timeout or a fault): nothing more is started on the GPU after that.  `trace(line)` is called before every case, so
+    that a run that dies names the case it died in."""
     failures, done, t0 = [], 0, time.time()
     for name, cfg, colls, *size in [c for c in CONFIGS if configs in c[0]] * repeat:
         bed.init_comms(cfg)
@@ -84,6 +85,8 @@ def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None, in_place=False
                 for op in OPS:
                     what = f"{name}: {NAMES[coll]} {orc.DT_NAMES[dt]} {orc.OP_NAMES[op]}"
                     done += 1
+                    if trace:
+                        trace(what)
                     try:
                         bad, plan = one(bed, coll, dt, op, size[0] if size else nbytes, in_place,
                                         (pad_elems * es(dt), pad_elems * es(dt)) if pad_elems else None)
@@ -100,6 +103,17 @@ def run(bed, nbytes, configs="", dtypes=None, repeat=1, log=None, in_place=False
     return failures
 
 
+def tracer_to(path):
+    """A trace function that appends each line to `path` and flushes it to the disk at once."""
+    f = open(path, "a")
+
+    def put(line):
+        f.write(line + "\n")
+        f.flush()
+        os.fsync(f.fileno())
+    return put
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ranks", type=int, default=8)
@@ -109,11 +123,13 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--in-place", action="store_true")
     ap.add_argument("--pad", type=int, default=0, help="elements in front of both user buffers (unaligned pointers)")
+    ap.add_argument("--trace", default="", help="file that receives one line before every case")
     args = ap.parse_args()
     bed = TestBed(args.ranks, env={"RCCL_AMD_SPIN_TIMEOUT_MS": "5000"})
+    tracer = tracer_to(args.trace) if args.trace else None
     try:
         failures = run(bed, args.bytes, args.configs, [int(x) for x in args.dtypes.split(",")] if args.dtypes else None,
-                       args.repeat, log=lambda m: print(m, flush=True), in_place=args.in_place, pad_elems=args.pad)
+                       args.repeat, log=lambda m: print(m, flush=True), in_place=args.in_place, pad_elems=args.pad, trace=tracer)
     finally:
         bed.close()
     print(f"DONE, {len(failures)} failures")
