@@ -185,23 +185,54 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kern_ms = float(t[0]), float(t[1])
 
-    # correctness spot check on the first elements (all-reduce): gather every rank's head over gloo
+    # Correctness of the timed path's last output (all-reduce), two ways:
+    #  - 64 windows of 4096 elements spread evenly over the whole bucket, the last one ending at the last element (every
+    #    channel and round of the schedule is met): every rank's windows are gathered over gloo and folded by the oracle;
+    #  - the WHOLE receive buffer on every rank against a fold computed on the device in rank order from the ranks'
+    #    buckets, which each rank regenerates from their seeds (a property check next to the oracle's: the number of
+    #    elements that differ must be zero on every rank).
     verified = None
     heads = None
+    whole_buffer_mismatches = None
+    sample_idx = None
     if args.coll == "allreduce" and not args.in_place and args.dtype == "fp32":
         import oracle as orc
-        head = sendbuf[:65536].float().cpu().numpy()
+        nwin, wlen = 64, min(4096, count)
+        starts = [(count - wlen) * k // (nwin - 1) for k in range(nwin)]
+        sample_idx = torch.cat([torch.arange(s, s + wlen, device="cuda") for s in starts])
+        head = sendbuf[sample_idx].float().cpu().numpy()
         if n > 1:
             heads = [None] * n
             dist.all_gather_object(heads, head)
         else:
             heads = [head]
         want = orc.host_fold(orc.F32, orc.SUM, heads)
-        got = recvbuf[:65536].float().cpu().numpy()
+        got = recvbuf[sample_idx].float().cpu().numpy()
         # the all-pairs schedule folds in rank order like the host fold: same bits; ring and chain orders differ
         # in the last place, so they are held to the reference's fp32 tolerance instead
         direct = n == 1 or comm.plan_info(0, count, dt_code)["algo"] == 0
         verified = bool(np.array_equal(got, want)) if direct else bool(orc.first_mismatch(orc.F32, got, want) < 0)
+        acc = None
+        for r in range(n):
+            if r == rank:
+                b = sendbuf
+            else:
+                g2 = torch.Generator(device="cuda")
+                g2.manual_seed(0x5EED0000 + r)
+                b = torch.rand(count, device="cuda", generator=g2, dtype=torch.float32) * 2 - 1
+            acc = b.clone() if acc is None else acc.add_(b)
+            del b
+        if direct:
+            bad = int((acc != recvbuf).sum().item())
+        else:
+            bad = int(((acc - recvbuf).abs() > n * n * 2.0 ** -24).sum().item())    # n - 1 roundings of sums below n
+        del acc
+        if n > 1:
+            tb = torch.tensor([bad], dtype=torch.int64)
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+            bad = int(tb[0])
+        whole_buffer_mismatches = bad
+        verified = verified and bad == 0
 
     per_step = wall / args.steps
     if args.coll == "allreduce":
@@ -269,6 +300,8 @@ def main():
                    "plan": comm.plan_info({"allreduce": 0, "reducescatter": 1, "allgather": 2, "broadcast": 3, "reduce": 4}[args.coll],
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,
+        "verification": {"oracle_windows": "64 x 4096 elements spread over the bucket, tail included",
+                         "whole_buffer_mismatches_all_ranks": whole_buffer_mismatches} if verified is not None else None,
         "roofline": {"bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": "GB/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes, "bound_note": bound_note},
@@ -277,7 +310,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and args.coll == "allreduce" and args.dtype == "fp32":
         import oracle as orc
         # the n host buckets: rank 0 regenerates every rank's bucket from its seed on its own GPU (same generator,
-        # same device model, same values) and keeps host copies; the first 65536 elements are compared with what the
+        # same device model, same values) and keeps host copies; the sampled windows are compared with what the
         # ranks themselves hold
         hosts = []
         same = True
@@ -291,7 +324,7 @@ def main():
                 hosts.append(t.cpu().numpy())
                 del t
             if heads is not None:
-                same = same and bool(np.array_equal(hosts[r][:65536], heads[r]))
+                same = same and bool(np.array_equal(hosts[r][sample_idx.cpu().numpy()], heads[r]))
         host_out = np.empty_like(hosts[0])
         orc.omp_sum_f32(hosts, host_out)                   # page in
         reps, t_cpu = 0, 0.0
