@@ -297,6 +297,8 @@ def main():
                                + ("" if n > 1 else " (1 rank: the reference path is a device copy; value is its S/t)"),
                    "ranks": n, "ranks_per_gpu": (n + ndev - 1) // ndev, "algbw_GBps": round(algbw, 3),
                    "registered_recvbuff": bool(reg_handle), "gather_phase_pieces": comm.stats() if n > 1 else None,
+                   # RCCL_AMD_TUNE_FLAGS=32: thread-0 stamps around the phases of every protocol step, averaged per role
+                   "step_timers_rank0": (comm.step_timers() or None) if n > 1 else None,
                    "plan": comm.plan_info({"allreduce": 0, "reducescatter": 1, "allgather": 2, "broadcast": 3, "reduce": 4}[args.coll],
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,
