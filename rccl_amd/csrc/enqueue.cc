@@ -195,9 +195,12 @@ ncclResult_t launchOne(const RaCollArgs& a) {
   w.root = a.root;
   w.pairRoles = p.pairRoles;
   w.oneShot = p.oneShot;
-  if (a.coll == RA_COLL_ALLREDUCE && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net)
+  // Registered receive buffers: the all-pairs all-reduce at every FIFO size; its ring and chain forms and both
+  // all-gathers from RA_AG_ANNOUNCE_BYTES on (the size from which their kernels exchange the registration words).
+  if (a.coll == RA_COLL_ALLREDUCE && p.proto == 0 && !c->net && c->nRanks > 1 &&
+      (p.algo == RA_ALGO_DIRECT || a.count * es >= RA_AG_ANNOUNCE_BYTES))
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
-  if (a.coll == RA_COLL_ALLGATHER && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net && a.count * es >= RA_AG_ANNOUNCE_BYTES)
+  if (a.coll == RA_COLL_ALLGATHER && p.proto == 0 && !c->net && c->nRanks > 1 && a.count * es >= RA_AG_ANNOUNCE_BYTES)
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es * (size_t)c->nRanks, a.stream, &w.regWord, &w.peerRegs));
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);

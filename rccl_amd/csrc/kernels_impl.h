@@ -1345,6 +1345,39 @@ struct RingPos {
   }
 };
 
+// Registered receive buffers on the ring and the chain (zero-copy circulation phase; the reference's Direct = 1
+// primitives, src/device/prims_simple.h:243-283, which it leaves off for its rings, src/device/all_reduce.h:62).
+// The rank that writes into my recvbuff is the one I receive finished pieces from (`from`), and it has to learn where
+// the buffer is after my launch has begun: for payloads of RA_AG_ANNOUNCE_BYTES and more (a rule every rank evaluates
+// alike, so the step counters stay in agreement) each workgroup that receives finished pieces first sends its
+// registration word to `from` on the kind-1 flags of that direction, which carry no data in these schedules, and each
+// workgroup that sends finished pieces (to `to`) waits for that word.  A sender that has the registration mapped writes
+// finished pieces straight into the peer's recvbuff and says so with the aux word of its first post; the receiver then
+// forwards from its own recvbuff instead of the FIFO slot and has nothing to copy for itself.
+// from < 0: this workgroup receives no finished pieces; to < 0: it sends none.  Sends before it waits: no cycle.
+__device__ __forceinline__ void announceRecvBuff(Ctx& cx, const RaWork& w, int from, int to) {
+  if (from >= 0) {
+    if (cx.tid == from) cx.sh->auxOut[from] = w.regWord;
+    cx.auxSend = 1;
+    cx.step(0, 0, 1u << from, 1, []() {});
+    cx.auxSend = 0;
+  }
+  if (to >= 0) {
+    cx.auxRecv = 1;
+    cx.step(1u << to, 1, 0, 0, [&]() {
+      if (cx.tid == to) {
+        const uint64_t base = regBaseOf(cx.comm, to, w.peerRegs ? cx.sh->auxIn[to] : 0);
+        cx.sh->directBase[to] = base;
+        cx.sh->auxOut[to] = base ? RA_AUX_DIRECT : 0;
+      }
+    });
+    cx.auxRecv = 0;
+  }
+}
+__device__ __forceinline__ void countPiece(const Ctx& cx, bool direct) {
+  if (cx.tid == 0) __hip_atomic_fetch_add(&cx.comm->stats[direct ? 0 : 1], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T, int OP>
 __device__ __forceinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
   const int n = uniformInt(cx.nRanks);
@@ -1353,16 +1386,22 @@ __device__ __forceinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
   const uint32_t pm = 1u << rp.prev, nm = 1u << rp.next;
   const T* in = (const T*)w.send;
   T* out = (T*)w.recv;
+  const bool announce = !cx.comm->netMode && R.count * sizeof(T) >= RA_AG_ANNOUNCE_BYTES && (size_t)cx.ch < R.nRounds;
+  if (announce) announceRecvBuff(cx, w, rp.prev, rp.next);
   for (size_t g = cx.ch; g < R.nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const bool first = announce && g == (size_t)cx.ch;
     size_t off, ne;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
-    // step 0: seed the piece behind me
+    // step 0: seed the piece behind me (its first post carries the "I write directly" word)
     R.piece(g, (rp.ix + n - 1) % n, off, ne);
+    cx.auxSend = first;
     cx.step(0, 0, nm, 0, [&]() {
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
       a.src[0] = uniformPtr((const char*)(in + off)); a.dst[0] = cx.sendSlot(rp.next, 0);
       rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
     });
+    cx.auxSend = 0;
+    cx.auxRecv = first;          // the first step that receives (always one of the reducing steps) reads that word
     // n-2 hops: local + received -> next
     for (int j = 2; j < n; j++) {
       R.piece(g, (rp.ix + n - j) % n, off, ne);
@@ -1372,33 +1411,49 @@ __device__ __forceinline__ void ringAllReduce(Ctx& cx, const RaWork& w) {
         a.dst[0] = cx.sendSlot(rp.next, 0);
         rcWG<T, OP, RC_HOP>(a, ne, cx.tid, cx.nthr);
       });
+      cx.auxRecv = 0;
     }
-    // my own piece: final value, kept and sent on
+    // my own piece: final value, kept and sent on (into the next rank's recvbuff when that is mapped here)
     R.piece(g, rp.ix, off, ne);
     cx.step(pm, 0, nm, 0, [&]() {
+      const uint64_t nb = uniform64(cx.sh->directBase[rp.next]);
       RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
       a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(rp.prev, 0);
-      a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
+      a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+      a.dst[1] = nb ? (char*)nb + off * sizeof(T) : cx.sendSlot(rp.next, 0);
       rcWG<T, OP, RC_HOP_KEEP>(a, ne, cx.tid, cx.nthr);
+      if (announce) countPiece(cx, nb != 0);
     });
+    cx.auxRecv = 0;
     // n-2 hops: keep and forward finished pieces
     for (int j = 1; j < n - 1; j++) {
       R.piece(g, (rp.ix + n - j) % n, off, ne);
       cx.step(pm, 0, nm, 0, [&]() {
-        RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
-        copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
+        const uint64_t nb = uniform64(cx.sh->directBase[rp.next]);
+        const bool here = uniform64(cx.sh->auxIn[rp.prev]) == RA_AUX_DIRECT;    // the piece already lies in my recvbuff
+        char* fwd = nb ? (char*)nb + off * sizeof(T) : cx.sendSlot(rp.next, 0);
+        RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+        if (here) {
+          a.src[0] = uniformPtr((const char*)(out + off)); a.dst[0] = fwd; a.nd = 1; a.nLocal = 0;
+          rcWG<int8_t, RA_OP_SUM, RC_SEND>(a, ne * sizeof(T), cx.tid, cx.nthr);
+        } else {
+          a.src[0] = cx.recvSlot(rp.prev, 0);
+          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = fwd; a.nd = 2;
+          copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
+        }
+        if (announce) countPiece(cx, nb != 0);
       });
     }
     // last finished piece
     R.piece(g, (rp.ix + 1) % n, off, ne);
     cx.step(pm, 0, 0, 0, [&]() {
+      if (uniform64(cx.sh->auxIn[rp.prev]) == RA_AUX_DIRECT) return;
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
       a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
       copyWG<CP_END>(a, ne * sizeof(T), cx.tid, cx.nthr);
     });
   }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // Ring reduce-scatter (src/device/reduce_scatter.h:36-57): blocks travel in the order
@@ -1440,7 +1495,8 @@ __device__ __forceinline__ void ringReduceScatter(Ctx& cx, const RaWork& w) {
   }
 }
 
-// Ring all-gather (src/device/all_gather.h:69-145), bytes.
+// Ring all-gather (src/device/all_gather.h:69-145), bytes.  Blocks of RA_AG_ANNOUNCE_BYTES and more go straight into
+// registered receive buffers (announceRecvBuff).
 __device__ __forceinline__ void ringAllGather(Ctx& cx, const RaWork& w) {
   const int n = uniformInt(cx.nRanks);
   const RingPos rp(cx);
@@ -1448,34 +1504,57 @@ __device__ __forceinline__ void ringAllGather(Ctx& cx, const RaWork& w) {
   const size_t nbytes = uniform64(w.count * w.elemSize);
   const size_t chunkB = uniform64(w.chunkElems * w.elemSize);
   const size_t nRounds = (nbytes + chunkB - 1) / chunkB;
+  const bool announce = !cx.comm->netMode && nbytes >= RA_AG_ANNOUNCE_BYTES && (size_t)cx.ch < nRounds;
+  if (announce) announceRecvBuff(cx, w, rp.prev, rp.next);
   for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const bool first = announce && g == (size_t)cx.ch;
     const size_t off = g * chunkB;
     const size_t nb = nbytes - off < chunkB ? nbytes - off : chunkB;
     cx.stepBytes = (uint32_t)nb;
+    cx.auxSend = first;
     cx.step(0, 0, nm, 0, [&]() {
+      const uint64_t nbase = uniform64(cx.sh->directBase[rp.next]);
       RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
       a.src[0] = uniformPtr(w.send + off);
       char* mine = uniformPtr(w.recv + (size_t)cx.rank * nbytes + off);
-      if (mine != a.src[0]) { a.dst[0] = mine; a.dst[1] = cx.sendSlot(rp.next, 0); a.nd = 2; a.nLocal = 1; }
-      else { a.dst[0] = cx.sendSlot(rp.next, 0); a.nd = 1; a.nLocal = 0; }
+      char* fwd = nbase ? (char*)nbase + (size_t)cx.rank * nbytes + off : cx.sendSlot(rp.next, 0);
+      if (mine != a.src[0]) { a.dst[0] = mine; a.dst[1] = fwd; a.nd = 2; a.nLocal = 1; }
+      else { a.dst[0] = fwd; a.nd = 1; a.nLocal = 0; }
       copyWG<CP_SPREAD>(a, nb, cx.tid, cx.nthr);
+      if (announce) countPiece(cx, nbase != 0);
     });
+    cx.auxSend = 0;
+    cx.auxRecv = first;          // the first step that receives reads the sender's "I write directly" word
     for (int j = 1; j < n - 1; j++) {
       const int blk = uniformInt(rp.order[(rp.ix + n - j) % n]);
       cx.step(pm, 0, nm, 0, [&]() {
-        RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
-        a.src[0] = cx.recvSlot(rp.prev, 0);
-        a.dst[0] = uniformPtr(w.recv + (size_t)blk * nbytes + off); a.nLocal = 1; a.dst[1] = cx.sendSlot(rp.next, 0);
-        copyWG<CP_FWD>(a, nb, cx.tid, cx.nthr);
+        const uint64_t nbase = uniform64(cx.sh->directBase[rp.next]);
+        const bool here = uniform64(cx.sh->auxIn[rp.prev]) == RA_AUX_DIRECT;    // the block already lies in my recvbuff
+        char* fwd = nbase ? (char*)nbase + (size_t)blk * nbytes + off : cx.sendSlot(rp.next, 0);
+        char* mine = uniformPtr(w.recv + (size_t)blk * nbytes + off);
+        RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+        if (here) {
+          a.src[0] = mine; a.dst[0] = fwd; a.nd = 1; a.nLocal = 0;
+          rcWG<int8_t, RA_OP_SUM, RC_SEND>(a, nb, cx.tid, cx.nthr);
+        } else {
+          a.src[0] = cx.recvSlot(rp.prev, 0);
+          a.dst[0] = mine; a.nLocal = 1; a.dst[1] = fwd; a.nd = 2;
+          copyWG<CP_FWD>(a, nb, cx.tid, cx.nthr);
+        }
+        if (announce) countPiece(cx, nbase != 0);
       });
+      cx.auxRecv = 0;
     }
     const int blk = uniformInt(rp.order[(rp.ix + 1) % n]);
     cx.step(pm, 0, 0, 0, [&]() {
+      if (uniform64(cx.sh->auxIn[rp.prev]) == RA_AUX_DIRECT) return;
       RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
       a.src[0] = cx.recvSlot(rp.prev, 0); a.dst[0] = uniformPtr(w.recv + (size_t)blk * nbytes + off); a.nLocal = 1;
       copyWG<CP_END>(a, nb, cx.tid, cx.nthr);
     });
+    cx.auxRecv = 0;
   }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // ------------------------------------------------------------------ chain ("tree") all-reduce
@@ -1496,7 +1575,16 @@ __device__ __forceinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int rol
   T* out = (T*)w.recv;
   const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
   const size_t nRounds = (count + chunk - 1) / chunk;
+  // Registered receive buffers: the finished chunk travels down from recvbuff to recvbuff.  The workgroups that send
+  // it down are the root's up workgroup and every other rank's down workgroup; the ones that receive it are the down
+  // workgroups (announceRecvBuff: word to the parent, then wait for the child's).
+  const bool announce = !cx.comm->netMode && count * sizeof(T) >= RA_AG_ANNOUNCE_BYTES && (size_t)cx.ch < nRounds;
+  if (announce) {
+    if (role == 0) { if (root) announceRecvBuff(cx, w, -1, child); }
+    else if (!root) announceRecvBuff(cx, w, parent, leaf ? -1 : child);
+  }
   for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
+    const bool first = announce && g == (size_t)cx.ch;
     const size_t off = g * chunk;
     const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
@@ -1515,31 +1603,51 @@ __device__ __forceinline__ void chainAllReduce(Ctx& cx, const RaWork& w, int rol
           rcWG<T, OP, RC_HOP>(a, ne, cx.tid, cx.nthr);
         });
       } else {
+        cx.auxSend = first;
         cx.step(1u << child, 0, 1u << child, 1, [&]() {
+          const uint64_t nb = uniform64(cx.sh->directBase[child]);
           RcArgs a; a.ns = 2; a.nd = 2; a.preIdx = 0; a.post = true; a.opArg = w.opArg;
           a.src[0] = uniformPtr((const char*)(in + off)); a.src[1] = cx.recvSlot(child, 0);
-          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
+          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
+          a.dst[1] = nb ? (char*)nb + off * sizeof(T) : cx.sendSlot(child, 1);
           rcWG<T, OP, RC_HOP_KEEP>(a, ne, cx.tid, cx.nthr);
+          if (announce) countPiece(cx, nb != 0);
         });
+        cx.auxSend = 0;
       }
     } else {
       if (root) continue;
+      cx.auxRecv = first;
       if (leaf) {
         cx.step(1u << parent, 1, 0, 0, [&]() {
+          if (uniform64(cx.sh->auxIn[parent]) == RA_AUX_DIRECT) return;
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
           a.src[0] = cx.recvSlot(parent, 1); a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
           copyWG<CP_END>(a, ne * sizeof(T), cx.tid, cx.nthr);
         });
       } else {
+        cx.auxSend = first;
         cx.step(1u << parent, 1, 1u << child, 1, [&]() {
-          RcArgs a; a.ns = 1; a.nd = 2; a.preIdx = -1; a.post = false; a.opArg = 0;
-          a.src[0] = cx.recvSlot(parent, 1);
-          a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = cx.sendSlot(child, 1);
-          copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
+          const uint64_t nb = uniform64(cx.sh->directBase[child]);
+          const bool here = uniform64(cx.sh->auxIn[parent]) == RA_AUX_DIRECT;     // the chunk already lies in my recvbuff
+          char* fwd = nb ? (char*)nb + off * sizeof(T) : cx.sendSlot(child, 1);
+          RcArgs a; a.ns = 1; a.preIdx = -1; a.post = false; a.opArg = 0;
+          if (here) {
+            a.src[0] = uniformPtr((const char*)(out + off)); a.dst[0] = fwd; a.nd = 1; a.nLocal = 0;
+            rcWG<int8_t, RA_OP_SUM, RC_SEND>(a, ne * sizeof(T), cx.tid, cx.nthr);
+          } else {
+            a.src[0] = cx.recvSlot(parent, 1);
+            a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1; a.dst[1] = fwd; a.nd = 2;
+            copyWG<CP_FWD>(a, ne * sizeof(T), cx.tid, cx.nthr);
+          }
+          if (announce) countPiece(cx, nb != 0);
         });
+        cx.auxSend = 0;
       }
+      cx.auxRecv = 0;
     }
   }
+  cx.auxRecv = 0; cx.auxSend = 0;
 }
 
 // ------------------------------------------------------------------ low-latency one-shot all-reduce

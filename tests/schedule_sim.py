@@ -270,9 +270,22 @@ def ring_pos(rings, ch, r, n):
     return order, ix, order[(ix - 1) % n], order[(ix + 1) % n]
 
 
-def ring_allreduce(n, r, ch, plan, count, rings, out):
+def announce_recv_buff(r, ch, frm, to):
+    """announceRecvBuff: the registration word goes to the rank that sends finished pieces (`frm`) on the kind-1 flags,
+    then the word of the rank this one sends them to (`to`) is awaited.  None: no such rank for this workgroup."""
+    if frm is not None:
+        yield Step(r, ch, [], [(frm, 1)], lambda read, write: write(frm, 1, "word"))
+    if to is not None:
+        def body(read, write):
+            assert read(to, 1) == "word"
+        yield Step(r, ch, [(to, 1)], [], body)
+
+
+def ring_allreduce(n, r, ch, plan, count, rings, out, elem_size=4):
     R = Rounds(count, plan["chunkElems"], plan["lastChunkElems"], n)
     _, ix, prev, nxt = ring_pos(rings, ch, r, n)
+    if count * elem_size >= AG_ANNOUNCE_BYTES and ch < R.nrounds:
+        yield from announce_recv_buff(r, ch, prev, nxt)
     for g in range(ch, R.nrounds, plan["nChannels"]):
         off, ne = R.piece(g, (ix - 1) % n)
         yield Step(r, ch, [], [(nxt, 0)], lambda read, write, off=off, ne=ne: write(nxt, 0, val(off, ne, {r})))
@@ -340,6 +353,8 @@ def ring_all_gather(n, r, ch, plan, nbytes, rings, out):
     chunk = plan["chunkElems"]
     order, ix, prev, nxt = ring_pos(rings, ch, r, n)
     nrounds = -(-nbytes // chunk)
+    if nbytes >= AG_ANNOUNCE_BYTES and ch < nrounds:
+        yield from announce_recv_buff(r, ch, prev, nxt)
     for g in range(ch, nrounds, plan["nChannels"]):
         off = g * chunk
         nb = min(chunk, nbytes - off)
@@ -367,11 +382,17 @@ def ring_all_gather(n, r, ch, plan, nbytes, rings, out):
 
 
 # ------------------------------------------------------------------ chain ("tree") all-reduce
-def chain_allreduce(n, r, role, ch, plan, count, rings, out):
+def chain_allreduce(n, r, role, ch, plan, count, rings, out, elem_size=4):
     chunk = plan["chunkElems"]
     order, ix, parent, child = ring_pos(rings, ch, r, n)
     root, leaf = ix == 0, ix == n - 1
     nrounds = -(-count // chunk)
+    if count * elem_size >= AG_ANNOUNCE_BYTES and ch < nrounds:
+        if role == 0:
+            if root:
+                yield from announce_recv_buff(r, ch, None, child)
+        elif not root:
+            yield from announce_recv_buff(r, ch, parent, None if leaf else child)
     for g in range(ch, nrounds, plan["nChannels"]):
         off = g * chunk
         ne = min(chunk, count - off)
@@ -442,7 +463,7 @@ def launch(net, coll, algo, plan, count, elem_size, rings, cus=256):
         elif algo == RING:
             for ch in range(C):
                 if coll == ALLREDUCE:
-                    progs.append(ring_allreduce(n, r, ch, plan, count, rings, out))
+                    progs.append(ring_allreduce(n, r, ch, plan, count, rings, out, elem_size))
                 elif coll == REDUCESCATTER:
                     progs.append(ring_reduce_scatter(n, r, ch, plan, count, rings, out))
                 else:
@@ -451,7 +472,7 @@ def launch(net, coll, algo, plan, count, elem_size, rings, cus=256):
         else:
             for role in (0, 1):
                 for ch in range(C):
-                    progs.append(chain_allreduce(n, r, role, ch, plan, count, rings, out))
+                    progs.append(chain_allreduce(n, r, role, ch, plan, count, rings, out, elem_size))
                     wgs += 1
         # every workgroup of a launch waits for workgroups elsewhere, so all must be resident: one per compute unit
         assert wgs == plan["grid"], (wgs, plan)
