@@ -139,21 +139,27 @@ def main():
     recvbuf = sendbuf if (args.in_place and args.coll == "allreduce") else torch.zeros(out_elems, device="cuda", dtype=tdt)
     stream = torch.cuda.current_stream()
     reg_handle = None
+    recv_arg, recv_raw = recvbuf, None
     if args.register and n > 1:
-        reg_handle = comm.register(recvbuf.data_ptr(), recvbuf.numel() * recvbuf.element_size())
+        # peers write only into fine-grained memory: the registered receive buffer comes from ncclMemAlloc (the launches
+        # get its address; it is copied into `recvbuf` for the checks afterwards)
+        if not (args.in_place and args.coll == "allreduce"):
+            recv_raw = ra.mem_alloc(out_elems * es)
+            recv_arg = recv_raw
+        reg_handle = comm.register(recv_raw if recv_raw else recvbuf.data_ptr(), out_elems * es)
         barrier()                                       # every rank's registration is published before the first launch
 
     def step():
         if args.coll == "allreduce":
-            comm.all_reduce(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
+            comm.all_reduce(sendbuf, recv_arg, count, dt_code, ra.ncclSum, stream)
         elif args.coll == "reducescatter":
-            comm.reduce_scatter(sendbuf, recvbuf, count, dt_code, ra.ncclSum, stream)
+            comm.reduce_scatter(sendbuf, recv_arg, count, dt_code, ra.ncclSum, stream)
         elif args.coll == "broadcast":
-            comm.broadcast(sendbuf, recvbuf, count, dt_code, 0, stream)
+            comm.broadcast(sendbuf, recv_arg, count, dt_code, 0, stream)
         elif args.coll == "reduce":
-            comm.reduce(sendbuf, recvbuf, count, dt_code, ra.ncclSum, 0, stream)
+            comm.reduce(sendbuf, recv_arg, count, dt_code, ra.ncclSum, 0, stream)
         else:
-            comm.all_gather(sendbuf, recvbuf, count, dt_code, stream)
+            comm.all_gather(sendbuf, recv_arg, count, dt_code, stream)
 
     try:
         for _ in range(args.warmup):
@@ -179,6 +185,12 @@ def main():
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch duration on the launch stream
     if comm.async_error() != 0:
         sys.exit(f"rank {rank}: the communicator reported an asynchronous error")
+    if recv_raw:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(ctypes.c_void_p(recvbuf.data_ptr()), ctypes.c_void_p(recv_raw), ctypes.c_size_t(out_elems * es), 3)
+        if rc != 0:
+            sys.exit(f"rank {rank}: hipMemcpy of the registered receive buffer failed ({rc})")
 
     if n > 1:
         t = torch.tensor([wall, kern_ms], dtype=torch.float64)
@@ -349,6 +361,8 @@ def main():
 
     if reg_handle:
         comm.deregister(reg_handle)
+    if recv_raw:
+        ra.mem_free(recv_raw)
     comm.destroy()
     if n > 1:
         dist.barrier()

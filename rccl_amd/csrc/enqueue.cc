@@ -202,6 +202,10 @@ ncclResult_t launchOne(const RaCollArgs& a) {
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es, a.stream, &w.regWord, &w.peerRegs));
   if (a.coll == RA_COLL_ALLGATHER && p.proto == 0 && !c->net && c->nRanks > 1 && a.count * es >= RA_AG_ANNOUNCE_BYTES)
     RA_CHECK(raRegPrepare(c, a.recv, a.count * es * (size_t)c->nRanks, a.stream, &w.regWord, &w.peerRegs));
+  // Reduce-scatter on the all-pairs FIFOs: a registered SEND buffer is read by the peers' reducers directly.
+  if (a.coll == RA_COLL_REDUCESCATTER && p.algo == RA_ALGO_DIRECT && p.proto == 0 && !c->net && c->nRanks > 1 &&
+      a.count * es >= RA_AG_ANNOUNCE_BYTES)
+    RA_CHECK(raRegPrepare(c, a.send, a.count * es * (size_t)c->nRanks, a.stream, &w.regWord, &w.peerRegs));
   RA_TRACE("rank %d coll %d count %zu dtype %d op %d algo %d ch %d chunk %zu last %zu grid %d", c->rank, a.coll, a.count,
            a.dtype, devOp, p.algo, p.nChannels, p.chunkElems, p.lastChunkElems, p.grid);
   hipError_t e;

@@ -887,6 +887,17 @@ struct Ctx {
     return (uint64_t*)(c->win[owner] + raFlagOffset(c->lay, which, ch, peer, kind));
   }
 
+  // Waits until the peers in `mask` have consumed every slot this workgroup published on the FIFOs of `kind` towards them
+  // (their credits have caught up with the send counters): a sender whose peers read its user buffer directly may not
+  // leave the kernel before.
+  __device__ __forceinline__ void awaitCredits(uint32_t mask, int kind) {
+    const int t = freshLane(tid);
+    const RaDevComm* c = freshComm(comm);
+    __syncthreads();
+    if (t < RA_MAX_RANKS && (mask >> t & 1)) raSpin(c, &sh->aborted, flagOf(c, rank, 1, t, kind), sh->sendStep[t][kind]);
+    __syncthreads();
+  }
+
   // One protocol step.  recvMask/sendMask: bit p set = peer p takes part.  Lane p of wave 0
   // waits for peer p's data (tail), lane 16+p waits for a free slot towards peer p (head).
   // `body()` runs on all threads between the waits and the posts; it reads recvSlot()s and
@@ -1131,6 +1142,15 @@ __device__ __forceinline__ void directAllReduce(Ctx& cx, LdsChan* sh0, LdsChan* 
 
 // Reduce-scatter: block j of sendbuff (count elements) belongs to rank j.  Round g covers
 // elements [g*chunk, (g+1)*chunk) of every block.  Roles: scatter, reduce.
+//
+// Registered send buffers (zero-copy scatter phase; the reference's direct-read primitives, src/device/prims_simple.h:
+// 243-283): a reducer that has a peer's sendbuff registration mapped reads that peer's contribution straight from the
+// sendbuff instead of from a FIFO slot, and the peer's scatter role then moves nothing for it.  For blocks of
+// RA_AG_ANNOUNCE_BYTES and more (a rule every rank evaluates alike) every scatter workgroup first sends its sendbuff's
+// registration word to every peer (kind 0), every reducer answers each sender whether it will read directly (kind 1),
+// and the scatter workgroup leaves the kernel only when the peers that read directly have consumed its last round (their
+// credits): until then the caller's sendbuff must stay as it is.  Not with a pre-multiplied sum: contributions read
+// from a sendbuff are not scaled yet, and the fold scales one source only.
 template <typename T, int OP>
 __device__ __forceinline__ void directReduceScatter(Ctx& cx, const RaWork& w, int role) {
   const int n = uniformInt(cx.nRanks), r = uniformInt(cx.rank);
@@ -1140,20 +1160,47 @@ __device__ __forceinline__ void directReduceScatter(Ctx& cx, const RaWork& w, in
   T* out = (T*)w.recv;
   const size_t count = uniform64(w.count), chunk = uniform64(w.chunkElems);
   const size_t nRounds = (count + chunk - 1) / chunk;
+  const bool announce = !cx.comm->netMode && count * sizeof(T) >= RA_AG_ANNOUNCE_BYTES && (size_t)cx.ch < nRounds;
+  if (announce && role == 0) {
+    if (cx.tid < n) cx.sh->auxOut[cx.tid] = w.regWord;
+    cx.auxSend = 1; cx.step(0, 0, peers, 0, []() {}); cx.auxSend = 0;
+    cx.auxRecv = 1; cx.step(peers, 1, 0, 0, []() {}); cx.auxRecv = 0;      // auxIn[p]: RA_AUX_DIRECT when p reads my sendbuff itself
+  } else if (announce) {
+    cx.auxRecv = 1;
+    cx.step(peers, 0, 0, 0, [&]() {
+      if (cx.tid < n && cx.tid != r) {
+        const int p = cx.tid;
+        const uint64_t base = (OP == RA_OP_PREMULSUM || !w.peerRegs) ? 0 : regBaseOf(cx.comm, p, cx.sh->auxIn[p]);
+        cx.sh->directBase[p] = base;
+        cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
+      }
+    });
+    cx.auxRecv = 0;
+    cx.auxSend = 1; cx.step(0, 0, peers, 1, []() {}); cx.auxSend = 0;
+  }
+  uint32_t readers = 0;          // scatter role: the peers that read my sendbuff themselves
+  if (announce && role == 0) {
+    RC_EACH(i, 0, n, if (i != r && uniform64(cx.sh->auxIn[i]) == RA_AUX_DIRECT) readers |= 1u << i;)
+  }
   for (size_t g = cx.ch; g < nRounds; g += (size_t)uniformInt(w.nChannels)) {
     const size_t off = g * chunk;
     const size_t ne = count - off < chunk ? count - off : chunk;
     cx.stepBytes = (uint32_t)(ne * sizeof(T));       // what a slot of this round carries (the host-staged proxy ships that much)
     if (role == 0) {
       cx.step(0, 0, peers, 0, [&]() {
-        RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
-        RC_EACH(i, 0, n - 1,
-          const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
-          pa.src[i] = uniformPtr((const char*)(in + (size_t)p * count + off)); pa.dst[i] = cx.sendSlot(p, 0);
-        )
-        if (OP != RA_OP_PREMULSUM) { pairCopyWG<true>(pa, ne * sizeof(T), cx.tid, cx.nthr); return; }
+        if (readers == peers) return;                  // every peer reads for itself: the post alone says "round g may be read"
+        if (OP != RA_OP_PREMULSUM && readers == 0) {
+          RcArgs pa; pa.ns = n - 1; pa.nd = n - 1; pa.preIdx = -1; pa.post = false; pa.opArg = 0;
+          RC_EACH(i, 0, n - 1,
+            const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;   // channels start on different links
+            pa.src[i] = uniformPtr((const char*)(in + (size_t)p * count + off)); pa.dst[i] = cx.sendSlot(p, 0);
+          )
+          pairCopyWG<true>(pa, ne * sizeof(T), cx.tid, cx.nthr);
+          return;
+        }
         for (int i = 0; i < n - 1; i++) {
           const int p = (r + 1 + (i + cx.ch) % (n - 1)) % n;
+          if (readers >> p & 1) continue;
           RcArgs a; a.ns = 1; a.nd = 1; a.preIdx = 0; a.post = false; a.opArg = w.opArg;
           a.src[0] = uniformPtr((const char*)(in + (size_t)p * count + off)); a.dst[0] = cx.sendSlot(p, 0);
           rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
@@ -1162,12 +1209,25 @@ __device__ __forceinline__ void directReduceScatter(Ctx& cx, const RaWork& w, in
     } else {
       cx.step(peers, 0, 0, 0, [&]() {
         RcArgs a; a.ns = n; a.nd = 1; a.preIdx = r; a.post = true; a.opArg = w.opArg;
-        RC_EACH(j, 0, n, a.src[j] = (j == r) ? uniformPtr((const char*)(in + (size_t)r * count + off)) : cx.recvSlot(j, 0);)
+        int nDirect = 0;
+        RC_EACH(j, 0, n,
+          if (j == r) a.src[j] = uniformPtr((const char*)(in + (size_t)r * count + off));
+          else {
+            const uint64_t base = uniform64(cx.sh->directBase[j]);
+            a.src[j] = base ? (const char*)base + ((size_t)r * count + off) * sizeof(T) : cx.recvSlot(j, 0);
+            nDirect += base != 0;
+          }
+        )
         a.dst[0] = uniformPtr((char*)(out + off)); a.nLocal = 1;
         rcWG<T, OP, RC_FOLD_ONE>(a, ne, cx.tid, cx.nthr);
+        if (announce && cx.tid == 0) {
+          if (nDirect) __hip_atomic_fetch_add(&cx.comm->stats[0], (uint64_t)nDirect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (n - 1 - nDirect) __hip_atomic_fetch_add(&cx.comm->stats[1], (uint64_t)(n - 1 - nDirect), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       });
     }
   }
+  if (readers) cx.awaitCredits(readers, 0);
 }
 
 // All-gather (bytes): roles: spread (my block into every peer's window and into my own

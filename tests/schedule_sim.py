@@ -209,10 +209,25 @@ def direct_allreduce(n, r, role, channels, plan, count, out):
         k += 1
 
 
-def direct_reduce_scatter(n, r, role, ch, plan, count, out):
+def direct_reduce_scatter(n, r, role, ch, plan, count, out, elem_size=4):
     chunk, C = plan["chunkElems"], plan["nChannels"]
     nrounds = -(-count // chunk)
     peers = [p for p in range(n) if p != r]
+    if count * elem_size >= AG_ANNOUNCE_BYTES and ch < nrounds:
+        # registered send buffers: the scatter role sends its word (kind 0) and waits for the reducers' answers (kind 1)
+        if role == 0:
+            yield Step(r, ch, [], [(p, 0) for p in peers], lambda read, write: [write(p, 0, "word") for p in peers])
+
+            def answers(read, write):
+                for p in peers:
+                    assert read(p, 1) == "answer"
+            yield Step(r, ch, [(p, 1) for p in peers], [], answers)
+        else:
+            def words(read, write):
+                for p in peers:
+                    assert read(p, 0) == "word"
+            yield Step(r, ch, [(p, 0) for p in peers], [], words)
+            yield Step(r, ch, [], [(p, 1) for p in peers], lambda read, write: [write(p, 1, "answer") for p in peers])
     for g in range(ch, nrounds, C):
         off = g * chunk
         ne = min(chunk, count - off)
@@ -453,7 +468,7 @@ def launch(net, coll, algo, plan, count, elem_size, rings, cus=256):
         elif algo == DIRECT and coll == REDUCESCATTER:
             for role in (0, 1):
                 for ch in range(C):
-                    progs.append(direct_reduce_scatter(n, r, role, ch, plan, count, out))
+                    progs.append(direct_reduce_scatter(n, r, role, ch, plan, count, out, elem_size))
                     wgs += 1
         elif algo == DIRECT:
             for role in (0, 1):

@@ -597,6 +597,63 @@ def test_registered_ring_all_gather_writes_blocks_directly(bed):
         assert stats[r]["direct_pieces"] == 0, (r, stats[r])
 
 
+def test_registered_send_buffers_are_read_directly_by_reduce_scatter(bed):
+    """Reduce-scatter with registered SEND buffers (the reference's direct-read primitives, src/device/prims_simple.h:
+    243-283): a reducer reads the peers' contributions straight from their sendbuffs, nothing goes through the FIFOs
+    (fifo_pieces == 0) and the senders stay in the kernel until they have been read.  Same bits as through the FIFOs;
+    mixed registration states, in place, coarse-grained memory, a pre-multiplied sum (never read directly) and blocks
+    below the size from which the words are exchanged."""
+    bed.init_comms({"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "NCCL_PROTO": "Simple"})
+    n = bed.nranks
+    count = (1 << 20) + 1056                 # 4 MiB fp32 per rank, several rounds, ragged
+    ins = [orc.fill_pattern(orc.F32, count * n, r) for r in range(n)]
+    plan = bed.plan(COLL_REDUCESCATTER, count, orc.F32)
+    assert plan["proto"] == 0 and plan["algo"] == ex.ALGO_DIRECT
+    want = [ex.reduce_scatter(orc.F32, orc.SUM, ins, r, plan) for r in range(n)]
+    for outs, stats in bed.run_registered(orc.F32, orc.SUM, count, ins, runs=2, coll=COLL_REDUCESCATTER):
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want[r], exact=True) is None, r
+            assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    for outs, stats in bed.run_registered(orc.F32, orc.SUM, count, ins, runs=2, coll=COLL_REDUCESCATTER, graph=True):
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want[r], exact=True) is None, r
+            assert stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    # only rank 0's sendbuff registered: every other reducer reads that one contribution directly
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[0], coll=COLL_REDUCESCATTER)
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want[r], exact=True) is None, r
+    assert stats[0]["direct_pieces"] == 0
+    for r in range(1, n):
+        assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == (n - 2) * stats[r]["direct_pieces"], (r, stats[r])
+    # in place (recvbuff = own block of the registered sendbuff), integer average
+    ins2 = [orc.fill_pattern(orc.I32, count * n, r) for r in range(n)]
+    want2 = [ex.reduce_scatter(orc.I32, orc.AVG, ins2, r, bed.plan(COLL_REDUCESCATTER, count, orc.I32)) for r in range(n)]
+    (outs, stats), = bed.run_registered(orc.I32, orc.AVG, count, ins2, in_place=True, coll=COLL_REDUCESCATTER)
+    for r in range(n):
+        assert ex.check(orc.I32, outs[r], want2[r], exact=True) is None, r
+        assert stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    # a float average is a pre-multiplied sum: contributions are scaled by their sender, so they travel through the FIFOs
+    want3 = [ex.reduce_scatter(orc.F32, orc.AVG, ins, r, plan) for r in range(n)]
+    (outs, stats), = bed.run_registered(orc.F32, orc.AVG, count, ins, coll=COLL_REDUCESCATTER)
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want3[r], exact=True) is None, r
+        assert stats[r]["direct_pieces"] == 0, (r, stats[r])
+    # nothing registered / coarse-grained memory: FIFOs, same bits
+    for kw in (dict(register_ranks=[]), dict(fine=False)):
+        (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, coll=COLL_REDUCESCATTER, **kw)
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want[r], exact=True) is None, (kw, r)
+            assert stats[r]["direct_pieces"] == 0, (kw, r, stats[r])
+    # below the threshold: no words, FIFOs
+    c4 = (128 << 10) + 16
+    ins4 = [orc.fill_pattern(orc.F32, c4 * n, r) for r in range(n)]
+    want4 = [ex.reduce_scatter(orc.F32, orc.SUM, ins4, r, bed.plan(COLL_REDUCESCATTER, c4, orc.F32)) for r in range(n)]
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, c4, ins4, coll=COLL_REDUCESCATTER)
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want4[r], exact=True) is None, r
+        assert stats[r]["direct_pieces"] == 0, (r, stats[r])
+
+
 def test_registered_all_gather_writes_blocks_directly(bed):
     """All-gather into registered receive buffers: blocks of 4 MiB and more are written by their owners straight into
     every registered recvbuff (no FIFO, no gather copy); smaller blocks, unregistered ranks and a ragged last chunk

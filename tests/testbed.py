@@ -12,6 +12,7 @@ Children import torch and the HIP library; the parent only needs numpy.
 import ctypes
 import multiprocessing as mp
 import os
+import sys
 import traceback
 
 import numpy as np
@@ -31,8 +32,16 @@ class _DevBuf:
     from torch's caching allocator), moved by torch."""
 
     _hip = None
+    staging = None          # diagnostic only (RCCL_AMD_BED_CHECK_READBACK): a device buffer as old as the process
+    # Coarse-grained buffers of the registered runs are cut from one tensor that is as old as the process.  A coarse
+    # buffer that torch has just obtained from hipMalloc, in a process that has allocated and freed fine-grained buffers
+    # before, intermittently reads back through the copy engine with zeros or an earlier fill in 128-byte runs while a
+    # kernel reads the right bytes at the same addresses (RCCL_AMD_BED_CHECK_READBACK=1 shows the two views side by
+    # side); allocations that live as long as the process have never shown it.
+    arena = None
+    arena_used = 0
 
-    def __init__(self, ra, nbytes, fine=False, fill=None, image=None):
+    def __init__(self, ra, nbytes, fine=False, fill=None, image=None, arena=False):
         import torch
         ctypes_hip()
         if image is not None:
@@ -42,6 +51,11 @@ class _DevBuf:
         if fine:
             self.p = ra.mem_alloc(max(self.n, 16))
             self.t = None
+        elif arena and _DevBuf.arena is not None and _DevBuf.arena_used + self.n + 4096 <= _DevBuf.arena.numel():
+            lo = _DevBuf.arena_used
+            _DevBuf.arena_used = (lo + max(self.n, 16) + 4095) // 4096 * 4096
+            self.t = _DevBuf.arena[lo:lo + max(self.n, 16)]
+            self.p = self.t.data_ptr()
         elif image is not None and self.n:
             self.t = torch.from_numpy(image).cuda()       # one host-to-device copy
             torch.cuda.synchronize()
@@ -86,7 +100,21 @@ class _DevBuf:
     def read(self):
         if self.t is not None:
             self.torch.cuda.synchronize()
-            return self.t[:self.n].cpu().numpy()
+            host = self.t[:self.n].cpu().numpy()
+            if os.environ.get("RCCL_AMD_BED_CHECK_READBACK") and _DevBuf.staging is not None and self.n <= _DevBuf.staging.numel():
+                # diagnostic: the same bytes read by a compute kernel into a long-lived buffer (allocated when the process
+                # started) against what the copy engine brought back from this buffer
+                st = _DevBuf.staging[:self.n]
+                self.torch.add(self.t[:self.n], 0, out=st)
+                self.torch.cuda.synchronize()
+                via_kernel = st.cpu().numpy()
+                if (via_kernel != host).any():
+                    bad = np.flatnonzero(via_kernel != host)
+                    sys.stderr.write(f"READBACK DIFFERS: the copy engine returned {bad.size} bytes (first at {int(bad[0])}, values "
+                                     f"{host[bad[:4]].tolist()}) that differ from what a kernel reads at the same addresses "
+                                     f"({via_kernel[bad[:4]].tolist()})\n")
+                    sys.stderr.flush()
+            return host
         out = np.empty(self.n, dtype=np.uint8)
         rc = self._hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(self.p), ctypes.c_size_t(self.n),
                                  ctypes.c_int(2))
@@ -102,12 +130,37 @@ class _DevBuf:
         self.p = 0
 
 
+class _DevView:
+    """A range of a _DevBuf (the in-place receive block of a reduce-scatter): same calls, nothing of its own to free."""
+
+    def __init__(self, buf, off, n):
+        self.buf, self.off, self.n = buf, int(off), int(n)
+
+    def data_ptr(self):
+        return self.buf.data_ptr() + self.off
+
+    def numel(self):
+        return self.n
+
+    def fill(self, value):
+        self.buf.fill(value, self.off, self.n)
+
+    def read(self):
+        return self.buf.read()[self.off:self.off + self.n]
+
+    def free(self):
+        pass
+
+
 def _child(rank, nranks, device, conn, env):
     try:
         os.environ.update(env)
         import torch
         import rccl_amd as ra
         torch.cuda.set_device(device)
+        if os.environ.get("RCCL_AMD_BED_CHECK_READBACK"):
+            _DevBuf.staging = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+        _DevBuf.arena = torch.empty(80 << 20, dtype=torch.uint8, device="cuda")
         comm = None
         stream = torch.cuda.Stream()
         while True:
@@ -374,35 +427,50 @@ def _child(rank, nranks, device, conn, env):
                 es = ra.TYPE_SIZE[a["dtype"]]
                 host_in = np.frombuffer(a["input"], dtype=np.uint8)
                 fine = a.get("fine", True)
-                if a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER:
-                    reg_out = _DevBuf(ra, host_in.size * nranks, fine, fill=0xA5)
+                reg_what = None
+                if a.get("coll", COLL_ALLREDUCE) == COLL_REDUCESCATTER:
+                    # the SEND buffer (nranks blocks) is the registered one: the peers' reducers read it directly
+                    src = _DevBuf(ra, host_in.size, fine, image=host_in, arena=True)
+                    block = host_in.size // nranks
+                    if a["in_place"]:
+                        reg_out, reg_bufs = _DevView(src, rank * block, block), [src]
+                    else:
+                        reg_out = _DevBuf(ra, block, fine, fill=0xA5, arena=True)
+                        reg_bufs = [reg_out, src]
+                    reg_in, reg_what = src.data_ptr(), src
+                elif a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER:
+                    reg_out = _DevBuf(ra, host_in.size * nranks, fine, fill=0xA5, arena=True)
                     if a["in_place"]:
                         reg_out.write(rank * host_in.size, host_in)
                         reg_in = reg_out.data_ptr() + rank * host_in.size
                         reg_bufs = [reg_out]
                     else:
-                        src = _DevBuf(ra, host_in.size, False, image=host_in)
+                        src = _DevBuf(ra, host_in.size, False, image=host_in, arena=True)
                         reg_in, reg_bufs = src.data_ptr(), [reg_out, src]
                 elif a["in_place"]:
-                    reg_out = _DevBuf(ra, host_in.size, fine, image=host_in)
+                    reg_out = _DevBuf(ra, host_in.size, fine, image=host_in, arena=True)
                     reg_in, reg_bufs = reg_out.data_ptr(), [reg_out]
                 else:
-                    src = _DevBuf(ra, host_in.size, False, image=host_in)
-                    reg_out = _DevBuf(ra, host_in.size, fine, fill=0xA5)
+                    src = _DevBuf(ra, host_in.size, False, image=host_in, arena=True)
+                    reg_out = _DevBuf(ra, host_in.size, fine, fill=0xA5, arena=True)
                     reg_in, reg_bufs = src.data_ptr(), [reg_out, src]
                 torch.cuda.synchronize()
-                reg_handle = comm.register(reg_out.data_ptr(), reg_out.numel()) if a["register_recv"] else None
+                reg_what = reg_what or reg_out
+                reg_handle = comm.register(reg_what.data_ptr(), reg_what.numel()) if a["register_recv"] else None
                 reg_state = (a, reg_in, reg_out, reg_handle, reg_bufs)
                 conn.send(("ok", None))
             elif cmd == "reg_run":
                 a, reg_in, reg_out, reg_handle, reg_bufs = reg_state
                 before = comm.stats()
                 gather = a.get("coll", COLL_ALLREDUCE) == COLL_ALLGATHER
+                scatter = a.get("coll", COLL_ALLREDUCE) == COLL_REDUCESCATTER
                 if not a["in_place"]:
                     reg_out.fill(0x5A)          # the owner's poison; no cache sweep follows: peers must still win
 
                 def launch():
-                    if gather:
+                    if scatter:
+                        comm.reduce_scatter(reg_in, reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
+                    elif gather:
                         comm.all_gather(reg_in, reg_out.data_ptr(), a["count"], a["dtype"], stream)
                     else:
                         comm.all_reduce(reg_in, reg_out.data_ptr(), a["count"], a["dtype"], a["op"], stream)
@@ -431,6 +499,7 @@ def _child(rank, nranks, device, conn, env):
                     comm.deregister(reg_handle)
                 for bf in reg_bufs:
                     bf.free()
+                _DevBuf.arena_used = 0
                 reg_state = None
                 conn.send(("ok", None))
             elif cmd == "probe_poison":
@@ -680,7 +749,7 @@ class TestBed:
                 assert err == 0, f"rank {r}: asynchronous error {err}"
             outs = [np.frombuffer(b, dtype=np.uint8) for _, b, _ in res]
             results.append((outs, [st for _, _, st in res]))
-            if in_place and coll == COLL_ALLREDUCE:
+            if in_place and coll in (COLL_ALLREDUCE, COLL_REDUCESCATTER):
                 break          # a second in-place run would reduce the first one's output
         self._all("reg_release", [None] * self.nranks)
         return results
