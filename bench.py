@@ -140,7 +140,19 @@ def main():
     stream = torch.cuda.current_stream()
     reg_handle = None
     recv_arg, recv_raw = recvbuf, None
-    if args.register and n > 1:
+    send_arg, send_raw = sendbuf, None
+    if args.register and n > 1 and args.coll == "reducescatter":
+        # the peers' reducers read a registered SEND buffer directly: it has to be fine-grained memory too
+        import ctypes
+        send_raw = ra.mem_alloc(in_elems * es)
+        rc = ctypes.CDLL("libamdhip64.so").hipMemcpy(ctypes.c_void_p(send_raw), ctypes.c_void_p(sendbuf.data_ptr()),
+                                                     ctypes.c_size_t(in_elems * es), 3)
+        if rc != 0:
+            sys.exit(f"rank {rank}: hipMemcpy into the registered send buffer failed ({rc})")
+        send_arg = send_raw
+        reg_handle = comm.register(send_raw, in_elems * es)
+        barrier()
+    elif args.register and n > 1:
         # peers write only into fine-grained memory: the registered receive buffer comes from ncclMemAlloc (the launches
         # get its address; it is copied into `recvbuf` for the checks afterwards)
         if not (args.in_place and args.coll == "allreduce"):
@@ -153,7 +165,7 @@ def main():
         if args.coll == "allreduce":
             comm.all_reduce(sendbuf, recv_arg, count, dt_code, ra.ncclSum, stream)
         elif args.coll == "reducescatter":
-            comm.reduce_scatter(sendbuf, recv_arg, count, dt_code, ra.ncclSum, stream)
+            comm.reduce_scatter(send_arg, recv_arg, count, dt_code, ra.ncclSum, stream)
         elif args.coll == "broadcast":
             comm.broadcast(sendbuf, recv_arg, count, dt_code, 0, stream)
         elif args.coll == "reduce":
@@ -363,6 +375,8 @@ def main():
         comm.deregister(reg_handle)
     if recv_raw:
         ra.mem_free(recv_raw)
+    if send_raw:
+        ra.mem_free(send_raw)
     comm.destroy()
     if n > 1:
         dist.barrier()
