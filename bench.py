@@ -323,6 +323,9 @@ def main():
                    "registered_recvbuff": bool(reg_handle), "gather_phase_pieces": comm.stats() if n > 1 else None,
                    # RCCL_AMD_TUNE_FLAGS=32: thread-0 stamps around the phases of every protocol step, averaged per role
                    "step_timers_rank0": (comm.step_timers() or None) if n > 1 else None,
+                   # NCCL_P2P_DISABLE=1: rank 0's proxy threads (tx / rx) since the communicator was made: ms inside send() and
+                   # recv() for slot data, ms idle / in poll(), messages, payload bytes
+                   "host_staged_proxy_rank0": (comm.net_stats() or None) if n > 1 else None,
                    "plan": comm.plan_info({"allreduce": 0, "reducescatter": 1, "allgather": 2, "broadcast": 3, "reduce": 4}[args.coll],
                                           count, dt_code) if n > 1 else {"algo": "local copy"}},
         "verified_against_oracle": verified,

@@ -330,6 +330,13 @@ ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, uint64_t*
  * workgroups and launches, per role (3 roles x {waiting for peers, reduce-copy body, draining memory operations,
  * fence and posting, number of steps}); ticks must hold 15 values. */
 ncclResult_t rcclAmdCommStepTimers(ncclComm_t comm, uint64_t* ticks);
+/* Host-staged (TCP) transport only: where the two proxy threads of this rank have spent their time since the
+ * communicator was made, 12 values: tx thread ns in send() for slot data, ns in send() for credits, ns in passes that
+ * found nothing to ship, ns in total, data messages, payload bytes, channel scans, scans skipped because the channel's
+ * stamp had not changed; rx thread ns in recv() for slot data, ns in poll(), ns in total, data messages.  All zero on a
+ * communicator that does not use the transport.  (The reference has no such query; its proxy progress is
+ * src/transport/net.cc:1123-1350 with the profiler hooks of src/proxy.cc.) */
+ncclResult_t rcclAmdCommNetStats(ncclComm_t comm, uint64_t* out);
 
 /* Rendezvous check without a GPU: joins the endpoint named by `id` as `rank` of `nranks`, all-gathers
  * `bytes` bytes per rank into `all`, and leaves.  It is the exchange ncclCommInitRank performs for the

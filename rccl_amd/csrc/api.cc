@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "comm.h"
+#include "net.h"
 #include "debug.h"
 #include "launch.h"
 #include "reg.h"
@@ -128,6 +129,13 @@ RA_API ncclResult_t rcclAmdCommStats(ncclComm_t comm, uint64_t* directPieces, ui
   }
   if (directPieces) *directPieces = v[0];
   if (fifoPieces) *fifoPieces = v[1];
+  return ncclSuccess;
+}
+
+RA_API ncclResult_t rcclAmdCommNetStats(ncclComm_t comm, uint64_t* out) {
+  RA_CHECK(raCommEnsureReady(comm, "rcclAmdCommNetStats"));
+  if (!out) return ncclInvalidArgument;
+  raNetStats(comm, out);
   return ncclSuccess;
 }
 

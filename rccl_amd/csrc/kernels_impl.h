@@ -978,6 +978,12 @@ struct Ctx {
           }
         }
         if (t == 0) { sh->recvDirty[rk] |= recvMask; sh->sendDirty[sk] |= sendMask; }
+        // host-staged transport: stamp the channel's word in this rank's own window behind the posts (the proxy thread
+        // looks at the stamps first and walks a channel's flag lines only when its stamp has changed)
+        if (c->netMode && ok && (recvMask | sendMask)) {
+          drainVmem();
+          if (t == 0) stFlag(flagOf(c, rank, 0, rank, 0), wall_clock64());
+        }
       }
       if (timed) {
         drainVmem();

@@ -21,9 +21,11 @@
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sched.h>
+#include <stdlib.h>
 #include <string.h>
 #include <strings.h>
 #include <sys/socket.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -35,6 +37,7 @@
 namespace {
 
 enum { MSG_DATA = 1, MSG_CREDIT = 2 };
+#define RA_NET_IDLE_SLEEP_US 20
 struct MsgHeader {
   uint32_t type, ch, kind, nbytes;
   uint64_t step;
@@ -63,6 +66,12 @@ inline uint64_t* flagAt(char* win, const RaWindowLayout& l, int which, int ch, i
   return (uint64_t*)(win + raFlagOffset(l, which, ch, peer, kind));
 }
 
+inline uint64_t nowNs() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 }  // namespace
 
 struct RaNet {
@@ -77,6 +86,11 @@ struct RaNet {
   std::atomic<bool> stop{false};
   std::atomic<bool> draining{false};     // shutdown has begun: tx leaves after a pass that found nothing left to ship
   std::atomic<uint64_t> bytesSent{0};
+  // Where the two proxy threads spend their time (nanoseconds since the communicator was made; rcclAmdCommNetStats):
+  // tx: inside send() for slot data / for credits, in passes that found nothing to ship (idle), everything else
+  // (looking at dirty words and flags); rx: inside recv() for slot data, waiting in poll(), everything else.
+  std::atomic<uint64_t> txSendNs{0}, txCreditNs{0}, txIdleNs{0}, txTotalNs{0}, txMsgs{0}, txScans{0}, txSkips{0};
+  std::atomic<uint64_t> rxRecvNs{0}, rxPollNs{0}, rxTotalNs{0}, rxMsgs{0};
 
   size_t ix(int p, int ch, int k) const { return ((size_t)p * lay.nChannels + ch) * RA_NKINDS + k; }
 
@@ -86,45 +100,89 @@ struct RaNet {
     if (c->hostFlags) __atomic_store_n(&c->hostFlags[0], 1u, __ATOMIC_RELAXED);   // kernels give up
   }
 
-  void txLoop() {
-    while (!stop.load(std::memory_order_relaxed)) {
-      bool progress = false;
-      for (int p = 0; p < n; p++) {
-        if (p == rank) continue;
-        char* sh = shadow[(size_t)p];
-        for (int ch = 0; ch < lay.nChannels; ch++)
-          for (int k = 0; k < RA_NKINDS; k++) {
-            // slots this rank's kernels published towards p
-            const uint64_t tail = __atomic_load_n(flagAt(sh, lay, 0, ch, rank, k), __ATOMIC_ACQUIRE);
-            uint64_t& st = sentTail[ix(p, ch, k)];
-            while (st < tail) {
-              const uint64_t step = st + 1;
-              const int slot = (int)((step - 1) % (uint64_t)lay.nSlots);
-              uint64_t nbytes = __atomic_load_n(flagAt(sh, lay, 2 + slot, ch, rank, k), __ATOMIC_RELAXED);
-              if (nbytes > lay.slotBytes) nbytes = lay.slotBytes;
-              MsgHeader h{MSG_DATA, (uint32_t)ch, (uint32_t)k, (uint32_t)nbytes, step};
-              const char* data = sh + raDataOffset(lay, ch, p, rank, k) + (size_t)slot * lay.slotBytes;
-              if (!sendAll(sock[(size_t)p], &h, sizeof h) || !sendAll(sock[(size_t)p], data, (size_t)nbytes)) { fail("send"); return; }
-              bytesSent += nbytes;
-              st = step;
-              progress = true;
-            }
-            // slots this rank's kernels consumed from p: credit back
-            const uint64_t head = __atomic_load_n(flagAt(sh, lay, 1, ch, rank, k), __ATOMIC_ACQUIRE);
-            uint64_t& shd = sentHead[ix(p, ch, k)];
-            if (shd < head) {
-              MsgHeader h{MSG_CREDIT, (uint32_t)ch, (uint32_t)k, 0, head};
-              if (!sendAll(sock[(size_t)p], &h, sizeof h)) { fail("send"); return; }
-              shd = head;
-              progress = true;
-            }
-          }
-      }
-      if (!progress) {
-        if (draining.load(std::memory_order_relaxed)) return;   // this rank's kernels are done and all of it is shipped
-        sched_yield();
+  // One look at everything this rank's kernels have posted on channel ch; ships what is new.  false: a send failed.
+  bool shipChannel(int ch, bool& progress) {
+    for (int p = 0; p < n; p++) {
+      if (p == rank) continue;
+      char* sh = shadow[(size_t)p];
+      for (int k = 0; k < RA_NKINDS; k++) {
+        // slots this rank's kernels published towards p
+        const uint64_t tail = __atomic_load_n(flagAt(sh, lay, 0, ch, rank, k), __ATOMIC_ACQUIRE);
+        uint64_t& st = sentTail[ix(p, ch, k)];
+        while (st < tail) {
+          const uint64_t step = st + 1;
+          const int slot = (int)((step - 1) % (uint64_t)lay.nSlots);
+          uint64_t nbytes = __atomic_load_n(flagAt(sh, lay, 2 + slot, ch, rank, k), __ATOMIC_RELAXED);
+          if (nbytes > lay.slotBytes) nbytes = lay.slotBytes;
+          MsgHeader h{MSG_DATA, (uint32_t)ch, (uint32_t)k, (uint32_t)nbytes, step};
+          const char* data = sh + raDataOffset(lay, ch, p, rank, k) + (size_t)slot * lay.slotBytes;
+          const uint64_t t0 = nowNs();
+          if (!sendAll(sock[(size_t)p], &h, sizeof h) || !sendAll(sock[(size_t)p], data, (size_t)nbytes)) { fail("send"); return false; }
+          txSendNs += nowNs() - t0;
+          txMsgs++;
+          bytesSent += nbytes;
+          st = step;
+          progress = true;
+        }
+        // slots this rank's kernels consumed from p: credit back
+        const uint64_t head = __atomic_load_n(flagAt(sh, lay, 1, ch, rank, k), __ATOMIC_ACQUIRE);
+        uint64_t& shd = sentHead[ix(p, ch, k)];
+        if (shd < head) {
+          MsgHeader h{MSG_CREDIT, (uint32_t)ch, (uint32_t)k, 0, head};
+          const uint64_t t0 = nowNs();
+          if (!sendAll(sock[(size_t)p], &h, sizeof h)) { fail("send"); return false; }
+          txCreditNs += nowNs() - t0;
+          shd = head;
+          progress = true;
+        }
       }
     }
+    return true;
+  }
+
+  // The kernels stamp one word per channel in this rank's own window (the flag line a rank would use for a FIFO to
+  // itself, which does not exist) after every batch of flag posts, behind the posts.  A pass looks at those nChannels
+  // words and walks the n x 2 kinds x 2 flag lines of a channel only when its stamp has changed; every few milliseconds,
+  // and while shutting down, a pass walks everything regardless.
+  void txLoop() {
+    std::vector<uint64_t> seen((size_t)lay.nChannels, 0);
+    const char* fs = getenv("RCCL_AMD_NET_FULL_SCAN");          // 1: walk every flag line in every pass (for comparison)
+    const bool always = fs && atoi(fs) != 0;
+    // After a run of passes with nothing to ship the thread sleeps between passes instead of yielding (microseconds;
+    // 0: always yield).  On a node with fewer cores than proxy threads a spinning tx thread takes the core the rx thread
+    // of another rank needs.
+    const char* sl = getenv("RCCL_AMD_NET_IDLE_SLEEP_US");
+    const long idleSleepUs = sl ? atol(sl) : RA_NET_IDLE_SLEEP_US;
+    int idlePasses = 0;
+    const uint64_t start = nowNs();
+    uint64_t lastFull = start;
+    while (!stop.load(std::memory_order_relaxed)) {
+      const uint64_t passStart = nowNs();
+      const bool full = always || draining.load(std::memory_order_relaxed) || passStart - lastFull > 2000000ull;
+      if (full) lastFull = passStart;
+      bool progress = false;
+      for (int ch = 0; ch < lay.nChannels; ch++) {
+        const uint64_t stamp = __atomic_load_n(flagAt(real, lay, 0, ch, rank, 0), __ATOMIC_ACQUIRE);
+        if (!full && stamp == seen[(size_t)ch]) { txSkips++; continue; }
+        seen[(size_t)ch] = stamp;
+        txScans++;
+        if (!shipChannel(ch, progress)) { txTotalNs = nowNs() - start; return; }
+      }
+      if (!progress) {
+        if (draining.load(std::memory_order_relaxed) && full) break;   // this rank's kernels are done and all of it is shipped
+        if (idleSleepUs > 0 && ++idlePasses > 64) {
+          struct timespec ts = {0, idleSleepUs * 1000};
+          nanosleep(&ts, nullptr);
+        } else {
+          sched_yield();
+        }
+        txIdleNs += nowNs() - passStart;
+      } else {
+        idlePasses = 0;
+      }
+      txTotalNs = nowNs() - start;
+    }
+    txTotalNs = nowNs() - start;
   }
 
   void rxLoop() {
@@ -132,8 +190,13 @@ struct RaNet {
     std::vector<int> who;
     for (int p = 0; p < n; p++)
       if (p != rank) { pf.push_back({sock[(size_t)p], POLLIN, 0}); who.push_back(p); }
+    const uint64_t start = nowNs();
     while (!stop.load(std::memory_order_relaxed)) {
+      const uint64_t p0 = nowNs();
       int r = ::poll(pf.data(), (nfds_t)pf.size(), 50);
+      const uint64_t p1 = nowNs();
+      rxPollNs += p1 - p0;
+      rxTotalNs = p1 - start;
       if (r < 0) { if (errno == EINTR) continue; fail("poll"); return; }
       if (r == 0) continue;
       for (size_t i = 0; i < pf.size(); i++) {
@@ -150,7 +213,10 @@ struct RaNet {
         if (h.type == MSG_DATA) {
           const int slot = (int)((h.step - 1) % (uint64_t)lay.nSlots);
           char* dst = real + raDataOffset(lay, (int)h.ch, rank, p, (int)h.kind) + (size_t)slot * lay.slotBytes;
+          const uint64_t r0 = nowNs();
           if (h.nbytes && !recvAll(pf[i].fd, dst, h.nbytes)) { if (!stop.load()) fail("recv"); return; }
+          rxRecvNs += nowNs() - r0;
+          rxMsgs++;
           __atomic_store_n(flagAt(real, lay, 0, (int)h.ch, p, (int)h.kind), h.step, __ATOMIC_RELEASE);
         } else if (h.type == MSG_CREDIT) {
           __atomic_store_n(flagAt(real, lay, 1, (int)h.ch, p, (int)h.kind), h.step, __ATOMIC_RELEASE);
@@ -253,6 +319,15 @@ ncclResult_t raNetSetup(ncclComm* c) {
   return ncclSuccess;
 }
 
+void raNetStats(ncclComm* c, uint64_t* out) {
+  RaNet* N = c->net;
+  for (int i = 0; i < RA_NET_STATS; i++) out[i] = 0;
+  if (!N) return;
+  out[0] = N->txSendNs; out[1] = N->txCreditNs; out[2] = N->txIdleNs; out[3] = N->txTotalNs; out[4] = N->txMsgs;
+  out[5] = N->bytesSent; out[6] = N->txScans; out[7] = N->txSkips;
+  out[8] = N->rxRecvNs; out[9] = N->rxPollNs; out[10] = N->rxTotalNs; out[11] = N->rxMsgs;
+}
+
 void raNetShutdown(ncclComm* c, bool drain) {
   RaNet* N = c->net;
   if (!N) return;
@@ -268,7 +343,11 @@ void raNetShutdown(ncclComm* c, bool drain) {
   for (int fd : N->sock) if (fd >= 0) ::close(fd);
   if (N->real) (void)hipHostFree(N->real);
   for (char* s : N->shadow) if (s) (void)hipHostFree(s);
-  RA_INFO("rank %d: host-staged transport shipped %llu payload bytes", c->rank, (unsigned long long)N->bytesSent.load());
+  RA_INFO("rank %d: host-staged transport shipped %llu payload bytes in %llu messages; tx thread %.1f ms in send() for data, %.1f ms for "
+          "credits, %.1f ms idle of %.1f ms (%llu channel scans, %llu skipped by their stamp); rx thread %.1f ms in recv() for data, "
+          "%.1f ms in poll() of %.1f ms", c->rank, (unsigned long long)N->bytesSent.load(), (unsigned long long)N->txMsgs.load(),
+          N->txSendNs / 1e6, N->txCreditNs / 1e6, N->txIdleNs / 1e6, N->txTotalNs / 1e6, (unsigned long long)N->txScans.load(),
+          (unsigned long long)N->txSkips.load(), N->rxRecvNs / 1e6, N->rxPollNs / 1e6, N->rxTotalNs / 1e6);
   delete N;
   c->net = nullptr;
 }

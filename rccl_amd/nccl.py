@@ -30,7 +30,7 @@ EXPORTS = [
     "ncclGetVersion", "ncclGetErrorString", "ncclGetLastError", "ncclCommGetAsyncError", "ncclGetUniqueId",
     "ncclCommInitRankConfig", "ncclCommInitRank", "ncclCommInitAll", "ncclCommFinalize", "ncclCommDestroy",
     "ncclCommAbort", "ncclCommCount", "ncclCommCuDevice", "ncclCommUserRank", "ncclMemAlloc", "ncclMemFree",
-    "ncclCommRegister", "ncclCommDeregister", "rcclAmdCommStats", "rcclAmdCommStepTimers",
+    "ncclCommRegister", "ncclCommDeregister", "rcclAmdCommStats", "rcclAmdCommStepTimers", "rcclAmdCommNetStats",
     "ncclRedOpCreatePreMulSum", "ncclRedOpDestroy", "ncclAllReduce", "ncclReduceScatter", "ncclAllGather",
     "ncclGroupStart", "ncclGroupEnd", "ncclReduce", "ncclBroadcast", "ncclBcast", "ncclSend", "ncclRecv",
     "ncclCommSplit", "ncclGather", "ncclScatter", "ncclAllToAll", "ncclAllToAllv", "mscclLoadAlgo", "mscclRunAlgo",
@@ -89,6 +89,7 @@ def lib():
         L.ncclCommRegister.argtypes = [vp, vp, sz, ctypes.POINTER(vp)]
         L.ncclCommDeregister.argtypes = [vp, vp]
         L.rcclAmdCommStepTimers.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        L.rcclAmdCommNetStats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
         L.rcclAmdCommStats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
         L.ncclRedOpCreatePreMulSum.argtypes = [ctypes.POINTER(ci), vp, ci, ci, vp]
         L.ncclRedOpDestroy.argtypes = [ci, vp]
@@ -301,6 +302,16 @@ class Communicator:
         d, f = ctypes.c_uint64(), ctypes.c_uint64()
         _check(lib().rcclAmdCommStats(self.handle, ctypes.byref(d), ctypes.byref(f)), "rcclAmdCommStats")
         return {"direct_pieces": d.value, "fifo_pieces": f.value}
+
+    def net_stats(self):
+        """rcclAmdCommNetStats: proxy-thread timers of the host-staged transport (ms) and counters; {} without it."""
+        v = (ctypes.c_uint64 * 12)()
+        _check(lib().rcclAmdCommNetStats(self.handle, v), "rcclAmdCommNetStats")
+        if not any(v):
+            return {}
+        return {"tx_send_data_ms": v[0] / 1e6, "tx_send_credit_ms": v[1] / 1e6, "tx_idle_ms": v[2] / 1e6, "tx_total_ms": v[3] / 1e6,
+                "tx_messages": v[4], "payload_bytes": v[5], "tx_channel_scans": v[6], "tx_scans_skipped": v[7],
+                "rx_recv_data_ms": v[8] / 1e6, "rx_poll_ms": v[9] / 1e6, "rx_total_ms": v[10] / 1e6, "rx_messages": v[11]}
 
     def step_timers(self):
         """With RCCL_AMD_TUNE_FLAGS=32: microseconds per step and role spent waiting / in the body / draining / posting."""
