@@ -12,8 +12,10 @@
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define RA_F8_FN __host__ __device__ __forceinline__
+#define RA_F8_UNROLL _Pragma("unroll")
 #else
 #define RA_F8_FN inline
+#define RA_F8_UNROLL
 #endif
 
 RA_F8_FN uint32_t raF2U(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -65,3 +67,77 @@ template <int WM> RA_F8_FN uint32_t f8EncodeOnGrid(float v) {
 
 // any float -> code (rccl_float8.h:48,221-229,412-415: round to nearest even, clip, NaN and infinity -> 0x80)
 template <int WM> RA_F8_FN uint32_t f8Encode(float v) { return f8EncodeOnGrid<WM>(f8Quantize<WM>(v)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fold of one dword (four codes) over its sources for sums and products, with the NaN code handled beside the
+// arithmetic: a NaN input makes the result NaN whatever else is folded (NaN + x, NaN * x, and a NaN scale factor), so
+// the float pipeline only ever sees finite values and needs no NaN or infinity cases (the largest product of two grid
+// values, and of a grid value with the scale factor, is far inside float's range), and the bytes of the result where
+// any source held the NaN code are set to it at the end.  Maxima and minima do not use this (fmaxf drops a NaN).
+
+// byte i of w -> float, for codes other than NaN (the NaN code 0x80 comes out as -0.0)
+template <int WM> RA_F8_FN float f8DecodeFinite(uint32_t w, int i) {
+  typedef F8Fmt<WM> F;
+  const uint32_t t = i == 3 ? w : w << (24 - 8 * i);                         // sign at bit 31, magnitude bits below it
+  const uint32_t m = (uint32_t)((int32_t)t >> (24 - F::DROP)) & (0x80000000u | (0x7fu << F::DROP));
+  return raU2F(m) * raU2F(F::DECODE_SCALE);
+}
+
+// finite float -> nearest grid value (round to nearest even, clipped), sign kept.  The float adder rounds: adding
+// 2^(E + 23 - WM) to |v| (E = v's exponent, at least that of the smallest normal) leaves exactly WM fraction bits.
+template <int WM> RA_F8_FN float f8QuantizeFinite(float v) {
+  typedef F8Fmt<WM> F;
+  const uint32_t u = raF2U(v);
+  uint32_t e = u & 0x7f800000u;
+  e = e > F::MIN_NORMAL ? e : F::MIN_NORMAL;
+  const float c = raU2F(e + (F::DROP << 23));
+  float r = (raU2F(u & 0x7fffffffu) + c) - c;
+  const float mx = raU2F(F::MAX_FINITE);
+  r = r < mx ? r : mx;
+  return raU2F((u & 0x80000000u) | raF2U(r));
+}
+
+// finite grid value -> code.  Dividing by the decode scale puts the 7 magnitude bits back at the top of a float's
+// exponent and mantissa fields (exactly, float denormals included); a zero magnitude has no sign.
+template <int WM> RA_F8_FN uint32_t f8EncodeFinite(float v) {
+  typedef F8Fmt<WM> F;
+  const uint32_t u = raF2U(v);
+  const float q = raU2F(u & 0x7fffffffu) * raU2F((uint32_t)(127 - (127 - F::BIAS)) << 23);     // 2^-(127 - BIAS)
+  const uint32_t m7 = (raF2U(q) >> F::DROP) & 0x7fu;
+  const uint32_t s = (u >> 24) & 0x80u;
+  return m7 | (s & (m7 + 0x7fu));
+}
+
+// bit 7 of every byte of the result: set where the byte of w is NOT the NaN code
+RA_F8_FN uint32_t f8NotNanBytes(uint32_t w) {
+  const uint32_t t = w ^ 0x80808080u;
+  return ((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t;
+}
+
+// R: 0 sum, 1 product (RA_OP_SUM / RA_OP_PROD).  ws[0..ns): the dword of every source; the source at preIdx is multiplied
+// by the scale factor whose code is kCode first (preIdx < 0: none).
+template <int WM, bool PROD, int NMAX>
+RA_F8_FN uint32_t f8FoldDword(const uint32_t (&ws)[NMAX], int ns, int preIdx, uint32_t kCode) {
+  const float k = f8DecodeFinite<WM>(kCode & 0xffu, 0);
+  uint32_t ok = f8NotNanBytes(ws[0]);
+  float st[4];
+  RA_F8_UNROLL for (int i = 0; i < 4; i++) {
+    st[i] = f8DecodeFinite<WM>(ws[0], i);
+    if (preIdx == 0) st[i] = f8QuantizeFinite<WM>(st[i] * k);
+  }
+  RA_F8_UNROLL for (int j = 1; j < NMAX; j++)
+    if (j < ns) {
+      ok &= f8NotNanBytes(ws[j]);
+      RA_F8_UNROLL for (int i = 0; i < 4; i++) {
+        float x = f8DecodeFinite<WM>(ws[j], i);
+        if (preIdx == j) x = f8QuantizeFinite<WM>(x * k);
+        st[i] = f8QuantizeFinite<WM>(PROD ? st[i] * x : st[i] + x);
+      }
+    }
+  uint32_t out = f8EncodeFinite<WM>(st[0]) | (f8EncodeFinite<WM>(st[1]) << 8) | (f8EncodeFinite<WM>(st[2]) << 16) |
+                 (f8EncodeFinite<WM>(st[3]) << 24);
+  uint32_t nan = (ok & 0x80808080u) ^ 0x80808080u;                 // 0x80 in every byte where a source held the NaN code
+  if (preIdx >= 0 && (kCode & 0xffu) == 0x80u) nan = 0x80808080u;  // a NaN scale factor
+  const uint32_t full = (nan >> 7) * 0xffu;
+  return (out & ~full) | nan;
+}

@@ -259,6 +259,19 @@ template <int WM, int OP> struct PackFold<f8_t<WM>, OP> {
   static constexpr int R = (OP == RA_OP_PREMULSUM || OP == RA_OP_SUMPOSTDIV) ? RA_OP_SUM : OP;
   template <int NMAX>
   static __device__ __forceinline__ u32x4 fold(const u32x4 (&src)[NMAX], int ns, int preIdx, uint64_t opArg, bool) {
+    if constexpr (R == RA_OP_SUM || R == RA_OP_PROD) {
+      // sums and products: the finite-path fold of f8_math.h, NaN codes tracked beside the arithmetic
+      u32x4 out;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        uint32_t ws[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) ws[j] = src[j][w];
+        out[w] = f8FoldDword<WM, R == RA_OP_PROD, NMAX>(ws, ns, OP == RA_OP_PREMULSUM ? preIdx : -1, (uint32_t)opArg);
+        __builtin_amdgcn_sched_barrier(0);       // one dword after the other: keeps the float temporaries of one dword apart from the next one's
+      }
+      return out;
+    }
     const float k = OP == RA_OP_PREMULSUM ? f8Decode<WM>((uint32_t)opArg) : 1.0f;
     u32x4 out;
 #pragma unroll
