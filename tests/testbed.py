@@ -160,7 +160,8 @@ def _child(rank, nranks, device, conn, env):
         torch.cuda.set_device(device)
         if os.environ.get("RCCL_AMD_BED_CHECK_READBACK"):
             _DevBuf.staging = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
-        _DevBuf.arena = torch.empty(80 << 20, dtype=torch.uint8, device="cuda")
+        if os.environ.get("RCCL_AMD_BED_ARENA_MIB"):
+            _DevBuf.arena = torch.empty(int(os.environ["RCCL_AMD_BED_ARENA_MIB"]) << 20, dtype=torch.uint8, device="cuda")
         comm = None
         stream = torch.cuda.Stream()
         while True:
