@@ -582,10 +582,11 @@ __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int ti
     const int shape = __builtin_amdgcn_readfirstlane(a.ns * 256 + a.nd * 16 + a.nLocal);
     bool done = false;
     // (the 8-bit floats are bound by their conversions, not by memory: they take the plain loop, one pack per thread, whose
-    // code is a fraction of the pipelined loops' and leaves the registers to the float temporaries)
+    // code is a fraction of the pipelined loops' and leaves the registers to the float temporaries; only their sums and
+    // products of one or two sources take the multi-pack loops, one tile at a time, which is as much as stays in registers)
 #define RC_TRY(NS, U, ND, LOC)                                                                  \
-    if constexpr (rcHas<SH>(NS, ND, LOC) && !IsF8<T>::value)                                      \
-      if (!done && shape == NS * 256 + ND * 16 + LOC) { rcCase<T, OP, LOC, NS, U, ND, PIPE>(a, npacks, tid, nthr, part, nparts); done = true; }
+    if constexpr (rcHas<SH>(NS, ND, LOC) && (!IsF8<T>::value || (NS <= 2 && (OP == RA_OP_SUM || OP == RA_OP_PROD))))  \
+      if (!done && shape == NS * 256 + ND * 16 + LOC) { rcCase<T, OP, LOC, NS, U, ND, PIPE && !IsF8<T>::value>(a, npacks, tid, nthr, part, nparts); done = true; }
     RC_TRY(1, 8, 1, 0) RC_TRY(1, 8, 1, 1) RC_TRY(2, 4, 1, 0) RC_TRY(2, 4, 1, 1) RC_TRY(4, 2, 1, 1) RC_TRY(8, 1, 1, 1)
     RC_TRY(2, 4, 2, 1) RC_TRY(4, 2, 4, 1) RC_TRY(8, 1, 8, 1)
 #undef RC_TRY
