@@ -24,9 +24,18 @@
 namespace {
 
 #define RA_BOARD_MAGIC 0x52414247u
-// Largest peer allocation mapped through HIP IPC.  With 2 GiB allocations hipIpcOpenMemHandle did not return within a
-// minute (ROCm 7.2, two processes on one MI355X); 1.5 GiB maps in milliseconds.
-#define RA_REG_MAX_IPC_BYTES (1ull << 31)
+// Largest peer allocation mapped through HIP IPC (RCCL_AMD_REG_MAX_IPC_BYTES overrides).  With the runtime's legacy IPC
+// mode allocations of 2 GiB and more did not come back from hipIpcOpenMemHandle within a minute (ROCm 7.2, two processes
+// on one MI355X; 1.5 GiB mapped in milliseconds).  With dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0) a bare process maps 2 and
+// 3 GiB in under a millisecond (tools/ipc_big_probe.py), but two benchmark processes (torch, a communicator, 2 GiB send
+// buffers registered) with the limit lifted did not get through their first launch within two minutes, so the limit stays.
+uint64_t maxIpcBytes() {
+  static const uint64_t v = []() -> uint64_t {
+    if (const char* e = getenv("RCCL_AMD_REG_MAX_IPC_BYTES")) { if (*e) return strtoull(e, nullptr, 0); }
+    return 1ull << 31;
+  }();
+  return v;
+}
 
 // One published registration.  `serial` is a per-entry sequence lock: 0 while the owner rewrites the
 // entry (and for an empty one), a fresh non-zero value once it is complete.
@@ -102,9 +111,10 @@ void* acquireMap(RaRegState* s, int p, const RegEntry& e, bool samePid) {
   m.base = e.base; m.refs = 1; m.ipc = !samePid; m.mapped = nullptr;
   if (samePid) {
     m.mapped = (void*)(uintptr_t)e.base;
-  } else if (e.size >= RA_REG_MAX_IPC_BYTES) {
-    RA_INFO("rank %d's registered allocation of %llu bytes is not mapped (allocations of 2 GiB and more did not come back from "
-            "hipIpcOpenMemHandle when tried): its pieces keep going through the FIFO", p, (unsigned long long)e.size);
+  } else if (e.size >= maxIpcBytes()) {
+    RA_INFO("rank %d's registered allocation of %llu bytes is not mapped (limit %llu: without dmabuf IPC, allocations of 2 GiB and "
+            "more did not come back from hipIpcOpenMemHandle when tried; RCCL_AMD_REG_MAX_IPC_BYTES): its pieces keep going through "
+            "the FIFO", p, (unsigned long long)e.size, (unsigned long long)maxIpcBytes());
     return nullptr;
   } else {
     hipError_t err = hipIpcOpenMemHandle(&m.mapped, e.handle, hipIpcMemLazyEnablePeerAccess);
