@@ -117,7 +117,12 @@ void* acquireMap(RaRegState* s, int p, const RegEntry& e, bool samePid) {
             "the FIFO", p, (unsigned long long)e.size, (unsigned long long)maxIpcBytes());
     return nullptr;
   } else {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    RA_INFO("mapping the %llu-byte allocation rank %d registered", (unsigned long long)e.size, p);
     hipError_t err = hipIpcOpenMemHandle(&m.mapped, e.handle, hipIpcMemLazyEnablePeerAccess);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    RA_INFO("mapped in %.1f ms (%s)", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) / 1e6, hipGetErrorString(err));
     if (err != hipSuccess) {
       (void)hipGetLastError();
       RA_INFO("cannot map a buffer registered by rank %d (%s): its pieces keep going through the FIFO", p, hipGetErrorString(err));
