@@ -1,6 +1,5 @@
 """Registered buffers on the ring, the chain and the reduce-scatter (zero-copy phases).  These tests allocate and free
-many fine-grained buffers of tens of MiB; they run in a bed (processes) of their own, whose coarse-grained buffers are cut
-from a tensor made when the processes start (see tests/testbed.py: _DevBuf.arena)."""
+many fine-grained buffers of tens of MiB; they run in a bed (processes) of their own."""
 import numpy as np
 import pytest
 
@@ -18,7 +17,7 @@ def _devices():
 
 @pytest.fixture(scope="module", params=[2, 4, 8])
 def bed(request):
-    tb = TestBed(request.param, devices=_devices(), env={"RCCL_AMD_BED_ARENA_MIB": "80"})
+    tb = TestBed(request.param, devices=_devices())
     yield tb
     tb.close()
 

@@ -33,11 +33,12 @@ class _DevBuf:
 
     _hip = None
     staging = None          # diagnostic only (RCCL_AMD_BED_CHECK_READBACK): a device buffer as old as the process
-    # Coarse-grained buffers of the registered runs are cut from one tensor that is as old as the process.  A coarse
-    # buffer that torch has just obtained from hipMalloc, in a process that has allocated and freed fine-grained buffers
-    # before, intermittently reads back through the copy engine with zeros or an earlier fill in 128-byte runs while a
-    # kernel reads the right bytes at the same addresses (RCCL_AMD_BED_CHECK_READBACK=1 shows the two views side by
-    # side); allocations that live as long as the process have never shown it.
+    # Coarse-grained test buffers are cut from one tensor that is as old as the process.  A coarse buffer that torch has
+    # just obtained from hipMalloc, in a process that has allocated and freed other buffers before, intermittently reads
+    # back through the copy engine with zeros or an earlier fill in 128-byte-aligned runs while a kernel reads the right
+    # bytes at the same addresses, or the other way round (RCCL_AMD_BED_CHECK_READBACK=1 shows the two views side by
+    # side; tools/fuzz_collectives.py with and without --arena-mib: 3 mismatches against 0 in the same 750 cases, in
+    # three different collectives and schedules).  Allocations that live as long as the process have never shown it.
     arena = None
     arena_used = 0
 
@@ -226,7 +227,7 @@ def _child(rank, nranks, device, conn, env):
 
                 def upload(image):
                     """One host-to-device copy per buffer (torch memory); it must read back as written."""
-                    b = _DevBuf(ra, 0, image=image)
+                    b = _DevBuf(ra, 0, image=image, arena=True)          # from the start-up arena when the bed has one
                     if not np.array_equal(b.read(), np.ascontiguousarray(image).view(np.uint8).ravel()):
                         raise RuntimeError("test bed: a host-to-device upload does not read back as written")
                     bufs.append(b)
@@ -349,6 +350,7 @@ def _child(rank, nranks, device, conn, env):
                 res = out_view().read()
                 for b in bufs:
                     b.free()
+                _DevBuf.arena_used = 0
                 for lo, hi in guards:
                     if not np.all(res[lo:hi] == 0xA5):
                         raise RuntimeError(f"rank {rank}: bytes outside the receive buffer were written (guard {lo}:{hi})")
@@ -657,8 +659,9 @@ class TestBed:
         per_gpu = -(-nranks // len(devices))
         # (with 8 processes on one GPU single launches were seen to stall for 0.5-3 s, in steps of about half a second,
         # while the driver rotated the processes' queues: the device-side wait limit leaves room for that)
+        # (every rank process makes one 200 MiB tensor when it starts and cuts its test buffers from it: _DevBuf.arena)
         base_env = {"RCCL_AMD_SPIN_TIMEOUT_MS": "30000", "RCCL_AMD_BOOTSTRAP_TIMEOUT_S": "60",
-                    "RCCL_AMD_NCHANNELS": str(max(2, min(16, 64 // per_gpu)))}
+                    "RCCL_AMD_NCHANNELS": str(max(2, min(16, 64 // per_gpu))), "RCCL_AMD_BED_ARENA_MIB": "200"}
         base_env.update(env or {})
         self.base_env = dict(base_env)
         self.conns, self.procs = [], []
