@@ -1,5 +1,5 @@
 #!/bin/bash
-# BASELINE.json's fifth configuration: ncclAllReduce sum fp32, 256 MiB, 8 ranks, every hop through pinned host memory
+# The host-staged benchmark configuration: ncclAllReduce sum fp32, 256 MiB, 8 ranks, every hop through pinned host memory
 # and loopback TCP (NCCL_P2P_DISABLE=1).  Bench line with the proxy threads' timers and the kernels' step timers.
 set -o pipefail
 O=gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Reduce-scatter and all-gather of BYTES (default 256 MiB) per rank with 8 ranks sharing ONE GPU (BASELINE.json's third configuration):
+# Reduce-scatter and all-gather of BYTES (default 256 MiB) per rank with 8 ranks sharing ONE GPU (the reduce-scatter + all-gather benchmark configuration):
 # FIFO path against registered buffers (reduce-scatter: send buffers read directly; all-gather: blocks written directly).
 set -o pipefail
 run() {  # coll algo flag
