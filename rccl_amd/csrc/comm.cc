@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 #include <strings.h>
 #include <unistd.h>
@@ -82,6 +83,10 @@ void readTunables(ncclComm* c) {
   long ch = envLong("RCCL_AMD_NCHANNELS", -1);
   if (ch < 0) ch = envLong("NCCL_MAX_NCHANNELS", dflt);
   long mn = envLong("NCCL_MIN_NCHANNELS", 1);
+  // ncclConfig_t::maxCTAs / minCTAs bound the channels of this one communicator (src/init.cc:2091-2100: a workgroup per
+  // channel there); a small maxCTAs is how a communicator made by ncclCommSplit is kept cheap (its window follows).
+  if (c->cfgMaxCTAs > 0 && ch > c->cfgMaxCTAs) ch = c->cfgMaxCTAs;
+  if (c->cfgMinCTAs > 0 && mn < c->cfgMinCTAs) mn = c->cfgMinCTAs;
   if (ch < mn) ch = mn;
   if (ch < 1) ch = 1;
   if (ch > RA_MAX_CHANNELS) ch = RA_MAX_CHANNELS;
@@ -695,6 +700,15 @@ ncclResult_t raCommInitRank(ncclComm_t* out, int nranks, const ncclUniqueId& id,
   ncclComm* c = new ncclComm;
   c->rank = rank; c->nRanks = nranks; c->device = device;
   c->blocking = wantsBlocking(config);
+  if (config && config->size >= offsetof(ncclConfig_t, maxCTAs) + sizeof(int)) {
+    if (config->minCTAs != NCCL_CONFIG_UNDEF_INT && config->minCTAs > 0) c->cfgMinCTAs = config->minCTAs;
+    if (config->maxCTAs != NCCL_CONFIG_UNDEF_INT && config->maxCTAs > 0) c->cfgMaxCTAs = config->maxCTAs;
+    if (c->cfgMinCTAs && c->cfgMaxCTAs && c->cfgMinCTAs > c->cfgMaxCTAs) {
+      RA_WARN("ncclCommInitRankConfig: minCTAs %d is larger than maxCTAs %d", c->cfgMinCTAs, c->cfgMaxCTAs);
+      c->magic = 0; delete c;
+      return ncclInvalidArgument;
+    }
+  }
   if (c->blocking) {
     const ncclResult_t res = initRankBody(c, id);
     if (res != ncclSuccess) { c->magic = 0; delete c; return res; }

@@ -54,6 +54,7 @@ struct ncclComm {
 
   // tunables (environment, read once at init)
   int maxChannels = 16;
+  int cfgMinCTAs = 0, cfgMaxCTAs = 0;   // ncclConfig_t::minCTAs / maxCTAs of this communicator (0: not given)
   int blockThreads = 512;
   int algoEnv = -1;          // NCCL_ALGO: -1 unset
   bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol

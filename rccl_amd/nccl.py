@@ -184,16 +184,18 @@ class Communicator:
         self.handle = handle
 
     @classmethod
-    def init_rank(cls, nranks, unique_id, rank, blocking=None):
+    def init_rank(cls, nranks, unique_id, rank, blocking=None, max_ctas=None, min_ctas=None):
         """ncclCommInitRank / ncclCommInitRankConfig on the current HIP device."""
         uid = ncclUniqueId()
         ctypes.memmove(ctypes.byref(uid), unique_id, NCCL_UNIQUE_ID_BYTES)
         h = ctypes.c_void_p()
-        if blocking is None:
+        if blocking is None and max_ctas is None and min_ctas is None:
             _check(lib().ncclCommInitRank(ctypes.byref(h), nranks, uid, rank), "ncclCommInitRank")
         else:
-            cfg = ncclConfig_t(ctypes.sizeof(ncclConfig_t), 0xcafebeef, 22105, int(blocking), -2**31, -2**31, -2**31,
-                               None, -2**31)
+            undef = -2**31
+            cfg = ncclConfig_t(ctypes.sizeof(ncclConfig_t), 0xcafebeef, 22105, undef if blocking is None else int(blocking), undef,
+                               undef if min_ctas is None else min_ctas, undef if max_ctas is None else max_ctas, None, undef)
+            blocking = True if blocking is None else blocking
             rc = lib().ncclCommInitRankConfig(ctypes.byref(h), nranks, uid, rank, ctypes.byref(cfg))
             if not (rc == ncclInProgress and not blocking):     # non-blocking: poll wait_ready() / async_error()
                 _check(rc, "ncclCommInitRankConfig")
@@ -214,10 +216,15 @@ class Communicator:
                 raise TimeoutError("communicator creation still in progress")
             time.sleep(0.0005)
 
-    def split(self, color, key):
-        """ncclCommSplit: the new communicator, or None for NCCL_SPLIT_NOCOLOR (-1)."""
+    def split(self, color, key, max_ctas=None):
+        """ncclCommSplit: the new communicator, or None for NCCL_SPLIT_NOCOLOR (-1).  max_ctas: ncclConfig_t::maxCTAs of the
+        new communicator (bounds its channels, and with them its window)."""
         h = ctypes.c_void_p()
-        rc = lib().ncclCommSplit(self.handle, color, key, ctypes.byref(h), None)
+        cfg = None
+        if max_ctas is not None:
+            undef = -2**31
+            cfg = ctypes.byref(ncclConfig_t(ctypes.sizeof(ncclConfig_t), 0xcafebeef, 22105, undef, undef, undef, max_ctas, None, undef))
+        rc = lib().ncclCommSplit(self.handle, color, key, ctypes.byref(h), cfg)
         if rc != ncclInProgress:
             _check(rc, "ncclCommSplit")
         return Communicator(h) if h.value else None

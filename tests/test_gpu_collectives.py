@@ -610,6 +610,12 @@ def test_comm_split_across_processes(bed):
             assert (size, new_rank, err) == (len(members), members.index(r), 0), (r, colors, keys, size, new_rank, err)
             want = len(members) * np.arange(count, dtype=np.int64) + 1000 * sum(members)
             assert np.array_equal(out.astype(np.int64), want), (r, colors, keys)
+    # ncclConfig_t::maxCTAs (src/init.cc:2091-2100) bounds the channels, and with them the window, of the new communicators
+    colors, keys = [0] * n, list(range(n))
+    for r, x in enumerate(bed.split(colors, keys, count, max_ctas=3)):
+        size, new_rank, err, out, channels = x
+        assert (size, new_rank, err) == (n, r, 0) and 1 <= channels <= 3, (r, x[:3], channels)
+        assert np.array_equal(out.astype(np.int64), n * np.arange(count, dtype=np.int64) + 1000 * sum(range(n))), r
     # the parent is unharmed
     _check_allreduce(bed, orc.F32, orc.SUM, 70000)
 

@@ -188,8 +188,9 @@ def _child(rank, nranks, device, conn, env):
                 conn.send(("ok", (comm.count(), comm.user_rank(), comm.cu_device())))
             elif cmd == "split":
                 # ncclCommSplit of the bed's communicator, one int32 all-reduce on the new one, then it is destroyed
-                color, key, count = args
-                sub = comm.split(color, key)
+                color, key, count = args[:3]
+                max_ctas = args[3] if len(args) > 3 else None
+                sub = comm.split(color, key, max_ctas=max_ctas)
                 if sub is None:
                     conn.send(("ok", None))
                 else:
@@ -199,7 +200,9 @@ def _child(rank, nranks, device, conn, env):
                     torch.cuda.synchronize()
                     sub.all_reduce(src, dst, count, ra.ncclInt32, ra.ncclSum, stream)
                     stream.synchronize()
-                    res = (sub.count(), sub.user_rank(), sub.async_error(), dst.cpu().numpy().tobytes())
+                    # (the channels the new communicator would use for a large all-reduce: ncclConfig_t::maxCTAs bounds them)
+                    big = sub.plan_info(COLL_ALLREDUCE, 1 << 28, ra.ncclFloat32)["nChannels"] if sub.count() > 1 else 0
+                    res = (sub.count(), sub.user_rank(), sub.async_error(), dst.cpu().numpy().tobytes(), big)
                     sub.destroy()
                     conn.send(("ok", res))
             elif cmd == "coll" and args.get("skip"):
@@ -773,12 +776,15 @@ class TestBed:
             assert errs == (0, 0), f"rank {r}: asynchronous errors {errs}"
         return [[np.frombuffer(b, dtype=np.uint8) for b in outs] for _, outs in res]
 
-    def split(self, colors, keys, count=4096):
+    def split(self, colors, keys, count=4096, max_ctas=None):
         """ncclCommSplit on every rank (colour -1: NCCL_SPLIT_NOCOLOR), then an int32 all-reduce of rank * 1000 + i on each
-        new communicator.  Returns per rank None or (new size, new rank, async error, result as int32 array)."""
+        new communicator.  Returns per rank None or (new size, new rank, async error, result as int32 array); with
+        max_ctas (ncclConfig_t::maxCTAs of the new communicators) also the channels they plan for a 1 GiB all-reduce."""
         if not self.inited:
             self.init_comms()
-        res = self._all("split", [(colors[r], keys[r], count) for r in range(self.nranks)])
+        res = self._all("split", [(colors[r], keys[r], count, max_ctas) for r in range(self.nranks)])
+        if max_ctas is not None:
+            return [None if x is None else (x[0], x[1], x[2], np.frombuffer(x[3], dtype=np.int32), x[4]) for x in res]
         return [None if x is None else (x[0], x[1], x[2], np.frombuffer(x[3], dtype=np.int32)) for x in res]
 
     def command(self, rank, cmd, args=None):
