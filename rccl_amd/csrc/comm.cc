@@ -759,6 +759,28 @@ ncclResult_t RaClique::gather(int rank, const void* mine, void* all, size_t byte
   return ncclSuccess;
 }
 
+uint64_t RaClique::barrierIn(int x) {
+  std::lock_guard<std::mutex> lk(m);
+  const uint64_t round = bRound;
+  bSum += x;
+  if (++bCount >= joined - left) {
+    bResult = bSum; bSum = 0; bCount = 0; bRound++;
+    xcv.notify_all();
+  }
+  return round;
+}
+
+ncclResult_t RaClique::barrierOut(uint64_t round, int* sum) {
+  std::unique_lock<std::mutex> lk(m);
+  if (!xcv.wait_for(lk, std::chrono::seconds(envLong("RCCL_AMD_BOOTSTRAP_TIMEOUT_S", 120)), [&]() { return bRound > round; })) {
+    RA_WARN("NCCL_LAUNCH_MODE=GROUP: the other ranks of this process did not reach the launch barrier");
+    return ncclRemoteError;
+  }
+  // bResult stays as it is until every sibling has arrived for the next round, which needs this one to return first
+  *sum = bResult;
+  return ncclSuccess;
+}
+
 ncclResult_t raCommSplit(ncclComm_t parent, int color, int key, ncclComm_t* newcomm, const ncclConfig_t* config) {
   struct Entry { int32_t color, key; };
   const int n = parent->nRanks;

@@ -33,6 +33,12 @@ struct RaClique {
   int xCount = 0;
   uint64_t xRound = 0;
   ncclResult_t gather(int rank, const void* mine, void* all, size_t bytes);
+  // Launch barrier of NCCL_LAUNCH_MODE=GROUP (src/group.cc:128-190, ncclCommIntraBarrierIn / Out): every sibling adds a
+  // number, the last one to arrive closes the round, everybody reads the round's sum.
+  int bCount = 0, bSum = 0, bResult = 0;
+  uint64_t bRound = 0;
+  uint64_t barrierIn(int x);                           // returns the round this arrival belongs to
+  ncclResult_t barrierOut(uint64_t round, int* sum);   // waits for that round to close
   ~RaClique();
 };
 

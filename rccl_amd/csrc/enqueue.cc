@@ -437,6 +437,55 @@ void raGroupAddSplit(ncclComm_t parent, int color, int key, ncclComm_t* newcomm,
   tInits.push_back(j);
 }
 
+// NCCL_LAUNCH_MODE (src/group.cc:128-190).  PARALLEL, the reference's default and this library's: every launch goes out as
+// its turn comes.  GROUP: the communicators of one process that belong to one job (siblings: made by one
+// ncclCommInitAll, or by ncclCommInitRank calls of one process) launch in rounds, one operation per communicator and
+// round, and nobody launches a round before every sibling has arrived for it, whichever threads drive them.
+bool launchModeGroup() {
+  static const bool group = []() { const char* e = getenv("NCCL_LAUNCH_MODE"); return e && !strcasecmp(e, "GROUP"); }();
+  return group;
+}
+
+ncclResult_t launchAll(const std::vector<RaCollArgs>& ops) {
+  ncclResult_t res = ncclSuccess;
+  if (!launchModeGroup()) {
+    for (const auto& a : ops) {
+      const ncclResult_t r = launchOne(a);
+      if (r != ncclSuccess && res == ncclSuccess) res = r;
+    }
+    return res;
+  }
+  // the communicators of this call in first-use order, each with its operations in issue order
+  std::vector<ncclComm*> comms;
+  std::vector<std::vector<const RaCollArgs*>> queue;
+  for (const auto& a : ops) {
+    size_t i = 0;
+    while (i < comms.size() && comms[i] != a.comm) i++;
+    if (i == comms.size()) { comms.push_back(a.comm); queue.emplace_back(); }
+    queue[i].push_back(&a);
+  }
+  std::vector<size_t> next(comms.size(), 0);
+  std::vector<uint64_t> round(comms.size(), 0);
+  for (size_t i = 0; i < comms.size(); i++)
+    if (comms[i]->clique) round[i] = comms[i]->clique->barrierIn(1);
+  while (true) {
+    bool more = false;
+    for (size_t i = 0; i < comms.size(); i++) {
+      int sum = next[i] < queue[i].size() ? 1 : 0;
+      if (comms[i]->clique) RA_CHECK(comms[i]->clique->barrierOut(round[i], &sum));
+      if (sum == 0) continue;                            // no sibling has anything left: this communicator is done
+      more = true;
+      if (next[i] < queue[i].size()) {
+        const ncclResult_t r = launchOne(*queue[i][next[i]++]);
+        if (r != ncclSuccess && res == ncclSuccess) res = r;
+      }
+      if (comms[i]->clique) round[i] = comms[i]->clique->barrierIn(next[i] < queue[i].size() ? 1 : 0);
+    }
+    if (!more) break;
+  }
+  return res;
+}
+
 ncclResult_t raGroupEnd() {
   if (tGroupDepth == 0) { RA_WARN("ncclGroupEnd: not in a group call"); return ncclInvalidUsage; }
   if (--tGroupDepth > 0) return ncclSuccess;
@@ -466,11 +515,8 @@ ncclResult_t raGroupEnd() {
   std::vector<RaCollArgs> ops;
   ops.swap(tPending);
   if (res != ncclSuccess && res != ncclInProgress) return res;   // an error inside the group cancels its launches
-  for (const auto& a : ops) {
-    ncclResult_t r = launchOne(a);
-    if (r != ncclSuccess && res == ncclSuccess) res = r;
-  }
-  return res;
+  const ncclResult_t lr = launchAll(ops);
+  return res == ncclSuccess ? lr : res;
 }
 
 ncclResult_t raEnqueue(const RaCollArgs& a) {
@@ -491,5 +537,6 @@ ncclResult_t raEnqueue(const RaCollArgs& a) {
   RA_INFO("%s: rank %d sendbuff %p recvbuff %p count %zu datatype %d op %d stream %p", names[a.coll], a.comm->rank,
           a.send, a.recv, a.count, a.dtype, a.op, (void*)a.stream);
   if (tGroupDepth > 0) { tPending.push_back(a); return ncclSuccess; }
+  if (launchModeGroup()) return launchAll(std::vector<RaCollArgs>(1, a));
   return launchOne(a);
 }

@@ -1,5 +1,7 @@
 """GPU parity of the reduce-copy core and the one-rank path against the CPU oracle.
 All calls go through the C ABI (rcclAmdReduceCopy, ncclAllReduce ...) via ctypes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -170,3 +172,13 @@ def test_register_cache_semantics():
         assert ra.lib().ncclCommRegister(None, None, 0, None) == ra.ncclInvalidArgument
     finally:
         comm.destroy()
+
+
+def test_launch_mode_group():
+    """NCCL_LAUNCH_MODE=GROUP (src/group.cc:128-190): sibling communicators of one process launch in rounds behind a
+    barrier, whichever threads drive them.  Runs in a process of its own (the mode is read once per process)."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "launch_mode_child.py")
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "launch mode group ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
