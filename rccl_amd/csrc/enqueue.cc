@@ -303,9 +303,9 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
     }
   }
   if (chunk * es >= 4096) chunk = alignUp(chunk, 1024 / es);
-  // Large steps in whole tiles of the reduce-copy loops (1024 threads x 16 bytes x packs per thread: 16 KiB with eight
-  // sources, 32 KiB with four, 64 KiB and 128 KiB with two): what is left over of a step runs one pack per thread.
-  const size_t tileBytes = n <= 2 ? (128u << 10) : n <= 4 ? (32u << 10) : (16u << 10);
+  // Large steps in whole tiles of the reduce-copy loops (1024 threads x 16 bytes x packs per thread: 64 KiB per source
+  // with three sources and more, 64 KiB and 128 KiB with two): what is left over of a step runs one pack per thread.
+  const size_t tileBytes = n <= 2 ? (128u << 10) : (64u << 10);
   if (chunk * es >= 4 * tileBytes) chunk = alignUp(chunk, tileBytes / es);
   if (chunk < minChunk) chunk = minChunk;
   if (chunk > maxChunk) {

@@ -397,7 +397,10 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
   const uint64_t opArg = uniform64(a.opArg);
   const bool post = __builtin_amdgcn_readfirstlane((int)a.post) != 0;
   const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
-  const uint32_t lane16 = (uint32_t)tid * 16u;          // this thread's byte offset inside a row of nthr packs
+  // this thread's byte offset inside a row of nthr packs: a copy the compiler cannot trace back to the lane number, so what
+  // is derived from it is computed in this call instead of once per kernel and kept in registers across every other loop
+  uint32_t lane16 = (uint32_t)tid * 16u;
+  asm volatile("" : "+v"(lane16));
   const uint32_t row = nthrU * 16u;                     // bytes between a thread's consecutive packs
   const size_t tile = (size_t)nthrU * U;
   size_t base = first;
@@ -498,6 +501,120 @@ __device__ __forceinline__ void rcPacks(const RcArgs& a, size_t npacksIn, size_t
   }
 }
 
+// Four and eight sources inside the collective kernels: one source after the other.  A tile is 4 packs per thread of ONE
+// source (64 KiB contiguous with 1024 threads), added into an accumulator tile while the next source's tile is in flight;
+// the destinations are written when all sources are in.  Same left-to-right association as the loop above.  Why: a
+// collective's workgroups each walk their own step, megabytes apart, so a launch keeps (workgroups x streams) DRAM
+// pages open at once; with one pack of every source per thread (16 KiB bursts per source) the 8-source fold of 240
+// workgroups measured 4.4-5.0 TB/s standalone, with 64 KiB bursts 5.1-5.9 TB/s (tools/mix_bench.hip).  (The local
+// kernels keep the loop above: their workgroups take consecutive tiles, which is sequential for the DRAM anyway.)
+// The bits of 1 in T: multiplying by it is the identity in every element type here, so a fold can scale every source,
+// the ones that need no scaling by 1, instead of choosing per pack between a scaled and an unscaled copy.
+template <typename T> __device__ __forceinline__ uint64_t oneBits() {
+  union { uint64_t u; T t; } x; x.u = 0; x.t = (T)1; return x.u;
+}
+template <> __device__ __forceinline__ uint64_t oneBits<bf16_t>() { return 0x3f80u; }
+template <> __device__ __forceinline__ uint64_t oneBits<f8e4m3_t>() { return 0; }     // (the 8-bit floats never take this path)
+template <> __device__ __forceinline__ uint64_t oneBits<f8e5m2_t>() { return 0; }
+
+// A uniform address pinned in scalar registers: the compiler may not fold it into per-lane 64-bit arithmetic, so the access
+// keeps the scalar-base + 32-bit lane-offset form.
+__device__ __forceinline__ uint64_t scalarBase(uint64_t v) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename T, int OP, int LOC, int NS, int ND>
+__device__ __forceinline__ void rcPacksSerial(const RcArgs& a, size_t npacksIn, size_t firstIn, size_t tileStepIn, int tid, int nthr) {
+  constexpr int U = 4;
+  static_assert(NS >= 3, "two sources are folded pack by pack");
+  const size_t npacks = uniform64(npacksIn), first = uniform64(firstIn), tileStep = uniform64(tileStepIn);
+  const int preIdx = __builtin_amdgcn_readfirstlane(a.preIdx);
+  const uint64_t opArg = uniform64(a.opArg);
+  const bool post = __builtin_amdgcn_readfirstlane((int)a.post) != 0;
+  const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
+  const uint32_t lane16 = (uint32_t)tid * 16u;
+  const uint32_t row = nthrU * 16u;
+  const size_t tile = (size_t)nthrU * U;
+  uint64_t s[NS], d[ND];
+#pragma unroll
+  for (int j = 0; j < NS; j++) s[j] = (uint64_t)uniformPtr(a.src[j]);
+#pragma unroll
+  for (int k = 0; k < ND; k++) d[k] = (uint64_t)uniformPtr(a.dst[k]);
+  size_t base = first;
+  for (; base + tile <= npacks; base += tileStep) {
+    const size_t b16 = base * 16;
+    // a copy of the lane offset the compiler cannot trace: address arithmetic stays inside the loop (scalar base + this one
+    // 32-bit offset) instead of being kept as per-lane 64-bit pointers across the whole kernel
+    uint32_t off = lane16;
+    asm volatile("" : "+v"(off));
+    u32x4 acc[U], x[U], y[U];
+    // (the row goes into the scalar base: one lane offset.  `after`: the loads may not be issued before that value exists —
+    // an empty asm ties the lane offset to it — so that never more than three tiles are live)
+    auto load = [&](u32x4 (&v)[U], int j, const u32x4& after) {
+      uint32_t o = off;
+      asm volatile("" : "+v"(o) : "v"(after));
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = ldAt(scalarBase(s[j] + b16 + (size_t)u * row), o);
+    };
+    auto fold = [&](const u32x4 (&v)[U], int j) {
+      // the factor of this source, chosen and kept in scalar registers (1 where the source needs no scaling)
+      const uint64_t factor = OP == RA_OP_PREMULSUM ? scalarBase(preIdx == j ? opArg : oneBits<T>()) : 0;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        u32x4 t = v[u];
+        if (OP == RA_OP_PREMULSUM) t = packPre<T>(t, factor);
+        acc[u] = packRed<T, OP>(acc[u], t);
+      }
+    };
+    const u32x4 none = {0, 0, 0, 0};
+    load(acc, 0, none);
+    load(x, 1, none);
+    if (OP == RA_OP_PREMULSUM) {
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = packPre<T>(acc[u], scalarBase(preIdx == 0 ? opArg : oneBits<T>()));
+    }
+#pragma unroll
+    for (int j = 1; j < NS; j += 2) {
+      if (j + 1 < NS) load(y, j + 1, j > 1 ? acc[U - 1] : none);      // behind the fold that freed y
+      fold(x, j);
+      if (j + 1 < NS) {
+        if (j + 2 < NS) load(x, j + 2, acc[U - 1]);                     // behind the fold that freed x
+        fold(y, j + 1);
+      }
+    }
+    if (OP == RA_OP_SUMPOSTDIV && post) {
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = packPost<T>(acc[u], opArg);
+    }
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+      if (k >= LOC) {
+#pragma unroll
+        for (int u = 0; u < U; u++) stSysAt(scalarBase(d[k] + b16 + (size_t)u * row), off, acc[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; u++) stAt(scalarBase(d[k] + b16 + (size_t)u * row), off, acc[u]);
+      }
+    }
+  }
+  // ragged end: the one tile that is not full, one pack per thread per pass
+  if (base < npacks) {
+    for (size_t i = base + tid; i < npacks; i += nthrU) {
+      u32x4 t[NS];
+#pragma unroll
+      for (int j = 0; j < NS; j++) t[j] = ldPack((const u32x4*)s[j] + i);
+      const u32x4 r = PackFold<T, OP>::template fold<NS>(t, NS, preIdx, opArg, post);
+#pragma unroll
+      for (int k = 0; k < ND; k++) {
+        if (k >= LOC) stSys((u32x4*)d[k] + i, r);
+        else stPack((u32x4*)d[k] + i, r);
+      }
+    }
+  }
+}
+
 // One element into a peer's window, system-scope write-through (see stSysAt).
 template <typename T> __device__ __forceinline__ void stSysElem(T* p, T v) {
   if constexpr (sizeof(T) == 1) { union { T t; uint8_t u; } x; x.t = v; const uint32_t w = x.u;
@@ -550,6 +667,15 @@ __device__ __forceinline__ void rcCase(const RcArgs& a, size_t npacks, int tid, 
   rcPacks<T, OP, LOC, NS, U, ND, PIPE>(a, lim, (size_t)part * tile, (size_t)nparts * tile, tid, nthr);
 }
 
+template <typename T, int OP, int LOC, int NS, int ND>
+__device__ __forceinline__ void rcCaseSerial(const RcArgs& a, size_t npacks, int tid, int nthr, int part, int nparts) {
+  const size_t tile = (size_t)nthr * 4;
+  const size_t nfull = npacks / tile;
+  const bool ownsRagged = (nfull % nparts) == (size_t)part;
+  const size_t lim = ownsRagged ? npacks : nfull * tile;
+  rcPacksSerial<T, OP, LOC, NS, ND>(a, lim, (size_t)part * tile, (size_t)nparts * tile, tid, nthr);
+}
+
 // Work-shared reduce-copy of `nelem` elements.  `part` of `nparts` workgroups take part
 // (the collectives use one workgroup: part 0 of 1; the local kernels use the whole grid).
 // The (sources, destinations, local destinations) shapes the schedules use at 2, 4 and 8 ranks get the pipelined loop
@@ -586,7 +712,11 @@ __device__ __forceinline__ void reduceCopy(const RcArgs& a, size_t nelem, int ti
     // products of one or two sources take the multi-pack loops, one tile at a time, which is as much as stays in registers)
 #define RC_TRY(NS, U, ND, LOC)                                                                  \
     if constexpr (rcHas<SH>(NS, ND, LOC) && (!IsF8<T>::value || (NS <= 2 && (OP == RA_OP_SUM || OP == RA_OP_PROD))))  \
-      if (!done && shape == NS * 256 + ND * 16 + LOC) { rcCase<T, OP, LOC, NS, U, ND, PIPE && !IsF8<T>::value>(a, npacks, tid, nthr, part, nparts); done = true; }
+      if (!done && shape == NS * 256 + ND * 16 + LOC) {                                           \
+        if constexpr (NS >= 4 && PIPE) rcCaseSerial<T, OP, LOC, NS, ND>(a, npacks, tid, nthr, part, nparts);             \
+        else rcCase<T, OP, LOC, NS, U, ND, PIPE && !IsF8<T>::value>(a, npacks, tid, nthr, part, nparts);                  \
+        done = true;                                                                              \
+      }
     RC_TRY(1, 8, 1, 0) RC_TRY(1, 8, 1, 1) RC_TRY(2, 4, 1, 0) RC_TRY(2, 4, 1, 1) RC_TRY(4, 2, 1, 1) RC_TRY(8, 1, 1, 1)
     RC_TRY(2, 4, 2, 1) RC_TRY(4, 2, 4, 1) RC_TRY(8, 1, 8, 1)
 #undef RC_TRY
@@ -699,7 +829,8 @@ static __device__ __forceinline__ void pairCopyWG(const RcArgs& a, size_t nbytes
   size_t done = 0;
   if (aligned) {
     const uint32_t nthrU = (uint32_t)__builtin_amdgcn_readfirstlane(nthr);
-    const uint32_t lane16 = (uint32_t)tid * 16u;
+    uint32_t lane16 = (uint32_t)tid * 16u;
+    asm volatile("" : "+v"(lane16));                    // (see rcPacks)
     const size_t row = (size_t)nthrU * 16;
     uint64_t s[RA_MAX_SRCS], d[RA_MAX_SRCS];
 #pragma unroll
@@ -707,25 +838,35 @@ static __device__ __forceinline__ void pairCopyWG(const RcArgs& a, size_t nbytes
       s[j] = uniform64((uint64_t)(j < np ? a.src[j] : a.src[0]));
       d[j] = uniform64((uint64_t)(j < np ? a.dst[j] : a.dst[0]));
     }
-    // spans of rows x pairs = up to 8 loads per thread, then what is left one row of every pair at a time
-    switch (np) {
-      case 1: done = pairRows<WT, 1, 8>(s, d, nbytes, lane16, row); break;
-      case 2: done = pairRows<WT, 2, 4>(s, d, nbytes, lane16, row); break;
-      case 3: done = pairRows<WT, 3, 2>(s, d, nbytes, lane16, row); break;
-      case 4: done = pairRows<WT, 4, 2>(s, d, nbytes, lane16, row); break;
-      default: break;
-    }
+    // One or two pairs: spans of rows x pairs = 8 loads per thread, then what is left one row of every pair at a time.
+    // Three pairs and more: one pair after the other in spans of 8 rows (128 KiB contiguous per stream) — a launch's
+    // workgroups each walk their own step, so the DRAM sees (workgroups x streams) open pages at once, and long bursts
+    // per stream beat sharing one load-latency ramp between the pairs (16 KiB bursts of 7 pairs: see rcPacksSerial).
+    if (np <= 2) {
+      switch (np) {
+        case 1: done = pairRows<WT, 1, 8>(s, d, nbytes, lane16, row); break;
+        default: done = pairRows<WT, 2, 4>(s, d, nbytes, lane16, row); break;
+      }
 #pragma unroll
-    for (int j = 0; j < RA_MAX_SRCS; j++) { s[j] += done; d[j] += done; }
-    switch (np) {
-      case 1: done += pairRows<WT, 1, 1>(s, d, nbytes - done, lane16, row); break;
-      case 2: done += pairRows<WT, 2, 1>(s, d, nbytes - done, lane16, row); break;
-      case 3: done += pairRows<WT, 3, 1>(s, d, nbytes - done, lane16, row); break;
-      case 4: done += pairRows<WT, 4, 1>(s, d, nbytes - done, lane16, row); break;
-      case 5: done += pairRows<WT, 5, 1>(s, d, nbytes - done, lane16, row); break;
-      case 6: done += pairRows<WT, 6, 1>(s, d, nbytes - done, lane16, row); break;
-      case 7: done += pairRows<WT, 7, 1>(s, d, nbytes - done, lane16, row); break;
-      default: done += pairRows<WT, 8, 1>(s, d, nbytes - done, lane16, row); break;
+      for (int j = 0; j < RA_MAX_SRCS; j++) { s[j] += done; d[j] += done; }
+      switch (np) {
+        case 1: done += pairRows<WT, 1, 1>(s, d, nbytes - done, lane16, row); break;
+        default: done += pairRows<WT, 2, 1>(s, d, nbytes - done, lane16, row); break;
+      }
+    } else {
+      // (one copy of the loops: the pair is picked with selects over constant indices, not by indexing the arrays)
+      size_t big = 0, rest = 0;
+#pragma nounroll
+      for (int j = 0; j < np; j++) {
+        uint64_t sj[1] = {s[0]}, dj[1] = {d[0]};
+#pragma unroll
+        for (int q = 1; q < RA_MAX_SRCS; q++)
+          if (q == j) { sj[0] = s[q]; dj[0] = d[q]; }
+        big = pairRows<WT, 1, 8>(sj, dj, nbytes, lane16, row);
+        sj[0] += big; dj[0] += big;
+        rest = pairRows<WT, 1, 1>(sj, dj, nbytes - big, lane16, row);
+      }
+      done = big + rest;
     }
   }
   // what is left (ragged end, or everything when a pointer is unaligned): pair by pair, bytes

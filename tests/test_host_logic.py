@@ -38,10 +38,10 @@ def test_plan_round_and_row_rules():
     with two ranks one round of the largest piece that fits a slot; payloads of more than a slot per channel take
     rounds of about equal size; small counts use only as many channels as have a full minimum chunk each."""
     f32 = ra.ncclFloat32
-    # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of 304 KiB (19 tiles of 16 KiB)
+    # 1 GiB, 8 ranks, 56 channels: four rounds would need 599 KiB chunks -> eight rounds of 320 KiB (5 tiles of 64 KiB)
     big = ra.plan_for_config(8, 0, 1 << 28, f32, max_channels=56)
     assert big["nChannels"] == 56 and big["grid"] == 168
-    assert big["chunkElems"] == 77824 and big["chunkElems"] * 4 % (16 << 10) == 0
+    assert big["chunkElems"] == 81920 and big["chunkElems"] * 4 % (64 << 10) == 0
     rounds = -(-(1 << 28) // (8 * 56 * big["chunkElems"]))
     assert rounds == 8
     # 1 GiB, 2 ranks, 32 channels: the slot bounds the chunk (512 KiB given here; 768 KiB is the library's default)
