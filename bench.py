@@ -75,8 +75,11 @@ def main():
     if per_gpu > 1:
         # Loop-back mode (several ranks on one GPU, for kernel work on a one-GPU box): the ranks share
         # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
-        # (two ranks: two workgroups per channel, otherwise three)
-        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if n == 2 else 80) // per_gpu)))
+        # Workgroups per channel: the ring has one, the chain two (up and down), the all-pairs schedule three for an
+        # all-reduce with three ranks and more and two otherwise (two ranks; reduce-scatter and all-gather).
+        algo = os.environ.get("NCCL_ALGO", "").lower()
+        wgs = 1 if algo == "ring" else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
+        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 256 // (wgs * per_gpu))))
 
     out = sys.stdout
     if n > 1:
