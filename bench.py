@@ -77,8 +77,13 @@ def main():
         # 256 CUs, so cap the channels to keep every workgroup of every rank resident.
         # Workgroups per channel: the ring has one, the chain two (up and down), the all-pairs schedule three for an
         # all-reduce with three ranks and more and two otherwise (two ranks; reduce-scatter and all-gather).
+        # (two ranks without NCCL_ALGO: the library takes the ring from 24 MiB, reduce-scatter / all-gather from 16 MiB per rank)
         algo = os.environ.get("NCCL_ALGO", "").lower()
-        wgs = 1 if algo == "ring" else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
+        two_rank_ring = (n == 2 and not algo and os.environ.get("RCCL_AMD_TWO_RANK_RING", "1") != "0"
+                         and not os.environ.get("NCCL_P2P_DISABLE")
+                         and ((args.coll == "allreduce" and args.bytes >= 24 << 20)
+                              or (args.coll in ("reducescatter", "allgather") and args.bytes >= 16 << 20)))
+        wgs = 1 if (algo == "ring" or two_rank_ring) else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
         os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 256 // (wgs * per_gpu))))
 
     out = sys.stdout

@@ -403,7 +403,21 @@ ncclResult_t raPlanFor(int n, int coll, size_t count, int dtype, int algoEnv, in
 }
 
 ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan* p) {
-  RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, c->algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
+  // Two ranks, large payloads, no NCCL_ALGO: the ring.  With two ranks the ring and the all-pairs schedule move the same
+  // bytes over the same link, but the ring's one workgroup per channel walks scatter, reduce and gather of its rounds
+  // itself, so no role waits for another to fill or empty its pipeline (two ranks sharing one GPU, all 256 compute units
+  // busy either way: all-reduce of 32 MiB 59 us against 71 us, 256 MiB 0.37 ms against 0.45 ms, 1 GiB 1.52 ms against
+  // 1.58 ms; reduce-scatter / all-gather of 16 MiB per rank 36 / 42 us against 42 / 51 us; below these sizes the
+  // one-exchange protocols win).  RCCL_AMD_TWO_RANK_RING=0 keeps the all-pairs schedule.
+  static const bool twoRankRing = []() { const char* e = getenv("RCCL_AMD_TWO_RANK_RING"); return !e || atoi(e) != 0; }();
+  int algoEnv = c->algoEnv;
+  if (algoEnv < 0 && c->nRanks == 2 && !c->net && twoRankRing) {
+    const size_t bytes = count * raTypeSize(dtype);
+    if ((coll == RA_COLL_ALLREDUCE && bytes >= (24u << 20)) ||
+        ((coll == RA_COLL_REDUCESCATTER || coll == RA_COLL_ALLGATHER) && bytes >= (16u << 20)))
+      algoEnv = RA_ALGO_RING;
+  }
+  RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
                      c->blockThreads, c->net || !c->allowLL ? 0 : c->explicitLL ? 2 : 1, c->lay.osBytes ? c->oneShotMaxBytes : 0,
                      c->lay.osBytes ? c->twoExMaxBytes : 0, p));
   if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }

@@ -357,6 +357,16 @@ def test_low_latency_protocol(bed):
         assert bed.plan(COLL_ALLREDUCE, 1250, orc.I32)["proto"] == (want_proto or 2)
         assert bed.plan(COLL_ALLREDUCE, 1 << 22, orc.F32)["proto"] in (0, 2, 3)  # mid-size: one or two exchanges, or the FIFO schedule
         assert bed.plan(COLL_ALLREDUCE, 1 << 26, orc.F32)["proto"] == 0          # large: always the three-phase FIFO protocol
+        # two ranks, no NCCL_ALGO: large payloads go around the ring (one workgroup per channel walks all three phases), smaller
+        # ones keep the all-pairs schedule and its one-exchange protocols; more ranks keep the all-pairs schedule throughout
+        ring = 1 if n == 2 else 0
+        assert bed.plan(COLL_ALLREDUCE, 6 << 20, orc.F32)["algo"] == ring         # 24 MiB
+        assert bed.plan(COLL_ALLREDUCE, (6 << 20) - 1, orc.F32)["algo"] == 0
+        assert bed.plan(COLL_REDUCESCATTER, 4 << 20, orc.F32)["algo"] == ring     # 16 MiB per rank
+        assert bed.plan(COLL_ALLGATHER, 4 << 20, orc.F32)["algo"] == ring
+        assert bed.plan(COLL_ALLGATHER, (4 << 20) - 1, orc.F32)["algo"] == 0
+        if proto is None and n == 2:
+            _check_allreduce(bed, orc.F32, orc.SUM, (6 << 20) + 1028)
         outs = bed.run(COLL_ALLREDUCE, orc.I32, orc.SUM, 1250, [x] * n, 1250 * 4, iters=7)
         for o in outs:
             assert np.array_equal(o.view(np.int32), n * x)

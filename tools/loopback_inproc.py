@@ -29,7 +29,10 @@ def main():
                  "use bench.py under torch.distributed.run (one process per rank) for more")
     os.environ["RCCL_AMD_MULTI_RANK_GPU"] = "1"
     os.environ.setdefault("RCCL_AMD_SPIN_TIMEOUT_MS", "20000")
-    os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (128 if a.ranks == 2 else 64) // a.ranks)))
+    # two workgroups per channel and rank on the all-pairs schedule, one on the ring (which two ranks take by default from 24 MiB)
+    ring = (os.environ.get("NCCL_ALGO", "").lower() == "ring"
+            or (not os.environ.get("NCCL_ALGO") and os.environ.get("RCCL_AMD_TWO_RANK_RING", "1") != "0" and a.bytes >= 24 << 20))
+    os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, (256 if ring else 128) // a.ranks)))
     import torch
     import rccl_amd as ra
     n, count = a.ranks, a.bytes // 4
