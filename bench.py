@@ -84,7 +84,11 @@ def main():
                          and ((args.coll == "allreduce" and args.bytes >= 24 << 20)
                               or (args.coll in ("reducescatter", "allgather") and args.bytes >= 16 << 20)))
         wgs = 1 if (algo == "ring" or two_rank_ring) else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
-        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 256 // (wgs * per_gpu))))
+        # A launch's workgroups are dealt round-robin to the 8 XCDs (32 compute units each, one 1024-thread workgroup per
+        # compute unit), so what has to fit is ranks x ceil(workgroups of one rank / 8) <= 32 per XCD: 3 ranks x 84
+        # workgroups is 252 in total but 33 on four of the XCDs; the 33rd waits for a compute unit that only frees up when
+        # a channel has finished (1 GiB at 3 ranks: 3.32 ms with 26 channels, 4.12 ms with 28; 7 ranks x 12 channels hung).
+        os.environ.setdefault("RCCL_AMD_NCHANNELS", str(max(2, 8 * (32 // per_gpu) // wgs)))
 
     out = sys.stdout
     if n > 1:

@@ -549,6 +549,10 @@ __device__ __forceinline__ void rcPacksSerial(const RcArgs& a, size_t npacksIn, 
     // 32-bit offset) instead of being kept as per-lane 64-bit pointers across the whole kernel
     uint32_t off = lane16;
     asm volatile("" : "+v"(off));
+    // (likewise the index of the scaled source: the per-source choice of the factor is then made here, tile by tile, in two
+    // scalar selects, instead of once for all sources in front of the loop with every factor kept in registers across it)
+    int preJ = preIdx;
+    asm volatile("" : "+s"(preJ));
     u32x4 acc[U], x[U], y[U];
     // (the row goes into the scalar base: one lane offset.  `after`: the loads may not be issued before that value exists —
     // an empty asm ties the lane offset to it — so that never more than three tiles are live)
@@ -560,7 +564,7 @@ __device__ __forceinline__ void rcPacksSerial(const RcArgs& a, size_t npacksIn, 
     };
     auto fold = [&](const u32x4 (&v)[U], int j) {
       // the factor of this source, chosen and kept in scalar registers (1 where the source needs no scaling)
-      const uint64_t factor = OP == RA_OP_PREMULSUM ? scalarBase(preIdx == j ? opArg : oneBits<T>()) : 0;
+      const uint64_t factor = OP == RA_OP_PREMULSUM ? scalarBase(preJ == j ? opArg : oneBits<T>()) : 0;
 #pragma unroll
       for (int u = 0; u < U; u++) {
         u32x4 t = v[u];
@@ -573,7 +577,7 @@ __device__ __forceinline__ void rcPacksSerial(const RcArgs& a, size_t npacksIn, 
     load(x, 1, none);
     if (OP == RA_OP_PREMULSUM) {
 #pragma unroll
-      for (int u = 0; u < U; u++) acc[u] = packPre<T>(acc[u], scalarBase(preIdx == 0 ? opArg : oneBits<T>()));
+      for (int u = 0; u < U; u++) acc[u] = packPre<T>(acc[u], scalarBase(preJ == 0 ? opArg : oneBits<T>()));
     }
 #pragma unroll
     for (int j = 1; j < NS; j += 2) {
