@@ -1991,7 +1991,10 @@ __device__ __forceinline__ void llFold(const RaDevComm* comm, const RaWork& w, c
           lp[j] = base + (u < nUnits ? u : u0) * 16;
         }
         if constexpr (U == 4) llLoadLines4(lp, line);
-        else line[0] = llLoadLine(lp[0]);
+        else {
+#pragma unroll
+          for (int j = 0; j < U; j++) line[j] = llLoadLine(lp[j]);
+        }
 #pragma unroll
         for (int j = 0; j < U; j++) {
           const size_t u = u0 + (size_t)j * gsize;
@@ -2072,7 +2075,8 @@ __global__ __launch_bounds__(RA_LL_THREADS) void raLLAllReduceKernel(const RaDev
   // one unit per thread and pass while every thread has at most one (payloads up to 128 KiB), four beyond that: the
   // loop is bound by the latency of the line loads (1 MiB at 2 ranks: 23 us one at a time, 16 us four at a time)
   if (folds) {
-    if (nUnits > gsize) llFold<T, OP, 4>(comm, w, mine, out, gather, buf, epoch, nUnits, gtid, gsize, dead);
+    // (the scaled sum of the 8-bit floats two at a time: with four, its float temporaries do not fit the registers)
+    if (nUnits > gsize) llFold<T, OP, (IsF8<T>::value && OP == RA_OP_PREMULSUM) ? 2 : 4>(comm, w, mine, out, gather, buf, epoch, nUnits, gtid, gsize, dead);
     else llFold<T, OP, 1>(comm, w, mine, out, gather, buf, epoch, nUnits, gtid, gsize, dead);
   }
   if (bcast) {

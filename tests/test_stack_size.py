@@ -14,8 +14,8 @@ import kernel_meta  # noqa: E402
 
 LIB = os.path.join(ROOT, "rccl_amd", "librccl_amd.so")
 FAMILIES = ("raCollKernel", "raOneShotKernel", "raTwoExchangeKernel", "raGatherKernel", "raLL", "raLocalKernel", "raNoAlloc")
-# the only kernels with a private segment: the line-protocol all-reduce of the two 8-bit floats with a scaled sum
-SMALL = {"raLLAllReduceKernel<f8_t<3>, 4>": 20, "raLLAllReduceKernel<f8_t<2>, 4>": 20}
+# kernels allowed a private segment, by demangled name: none
+SMALL = {}
 
 
 @pytest.fixture(scope="module")
