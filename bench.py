@@ -83,7 +83,8 @@ def main():
                          and not os.environ.get("NCCL_P2P_DISABLE")
                          and ((args.coll == "allreduce" and args.bytes >= 24 << 20)
                               or (args.coll in ("reducescatter", "allgather") and args.bytes >= 16 << 20)))
-        wgs = 1 if (algo == "ring" or two_rank_ring) else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
+        fused = os.environ.get("RCCL_AMD_FUSED_ROLES", "0") != "0" and n > 2 and args.coll == "allreduce" and algo in ("", "direct")
+        wgs = 1 if (algo == "ring" or two_rank_ring or fused) else 2 if (algo == "tree" or n == 2 or args.coll != "allreduce") else 3
         # A launch's workgroups are dealt round-robin to the 8 XCDs (32 compute units each, one 1024-thread workgroup per
         # compute unit), so what has to fit is ranks x ceil(workgroups of one rank / 8) <= 32 per XCD: 3 ranks x 84
         # workgroups is 252 in total but 33 on four of the XCDs; the 33rd waits for a compute unit that only frees up when

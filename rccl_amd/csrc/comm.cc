@@ -104,6 +104,7 @@ void readTunables(ncclComm* c) {
   c->maxChannels = (int)ch;
   long nt = envLong("RCCL_AMD_NTHREADS", envLong("NCCL_NTHREADS", 1024));
   c->blockThreads = nt <= 256 ? 256 : nt <= 512 ? 512 : 1024;
+  c->fusedRoles = envLong("RCCL_AMD_FUSED_ROLES", 0) != 0;
   c->minChunkBytes = (size_t)envLong("RCCL_AMD_MIN_CHUNK_BYTES", 32 << 10);
   if (c->minChunkBytes < 1024) c->minChunkBytes = 1024;
   exchangeLimits(c);

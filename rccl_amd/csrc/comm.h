@@ -65,6 +65,7 @@ struct ncclComm {
   int algoEnv = -1;          // NCCL_ALGO: -1 unset
   bool allowLL = true;       // NCCL_PROTO permits the low-latency protocol
   bool explicitLL = false;   // NCCL_PROTO names LL and nothing else: small payloads take it under NCCL_ALGO=Ring|Tree too
+  bool fusedRoles = false;   // RCCL_AMD_FUSED_ROLES: one workgroup per channel for the all-pairs all-reduce
   int llGrid = RA_LL_GRID;   // workgroups of a low-latency launch (the same on every rank of the communicator)
   size_t minChunkBytes = 32 << 10;
   size_t oneShotMaxBytes = 0;  // all-reduces up to this size (and above the low-latency limit) run as one exchange

@@ -420,6 +420,12 @@ ncclResult_t raPlan(const ncclComm* c, int coll, size_t count, int dtype, RaPlan
   RA_CHECK(raPlanFor(c->nRanks, coll, count, dtype, algoEnv, c->maxChannels, c->lay.slotBytes, c->minChunkBytes,
                      c->blockThreads, c->net || !c->allowLL ? 0 : c->explicitLL ? 2 : 1, c->lay.osBytes ? c->oneShotMaxBytes : 0,
                      c->lay.osBytes ? c->twoExMaxBytes : 0, p));
+  // RCCL_AMD_FUSED_ROLES=1: the all-pairs all-reduce with one workgroup per channel that walks scatter, reduce and gather
+  // itself (directAllReduce, role 3) instead of three workgroups per channel.
+  if (c->fusedRoles && coll == RA_COLL_ALLREDUCE && p->algo == RA_ALGO_DIRECT && p->proto == 0 && !p->oneShot && !p->pairRoles && !c->net) {
+    p->pairRoles = 2;
+    p->grid = p->nChannels;
+  }
   if (p->proto == 1) { p->nChannels = c->llGrid; p->grid = c->llGrid; }
   if (p->proto >= 2) { p->nChannels = c->osGrid; p->grid = c->osGrid; }
   return ncclSuccess;

@@ -1218,19 +1218,28 @@ __device__ __forceinline__ void directAllReduce(Ctx& cx, LdsChan* sh0, LdsChan* 
   // straight into the peer's recvbuff and says so with its first broadcast-phase post, and the peer's gather role
   // then has nothing to copy for it.  The words travel beside the FIFO slots, once per launch and channel.
   const bool words = !cx.comm->netMode;
-  if (role == 0 && cx.tid < n) {
+  if ((role == 0 || role == 3) && cx.tid < n) {
     sh0->auxOut[cx.tid] = w.regWord;
     if (nCtx > 1) sh1->auxOut[cx.tid] = w.regWord;
   }
+  // Role 3: the workgroup walks all three roles of its channel, skewed by one round each — scatter of round k, reduce of
+  // round k - 1, gather of round k - 2 — so that what a step waits for was produced by the peers one iteration earlier.
+  // Every rank runs the same sequence and a step depends only on steps of earlier iterations, so two slots per FIFO suffice.
+  const int nPh = role == 3 ? 3 : 1;
   const size_t stride = (size_t)uniformInt(w.nChannels);
-  for (size_t k = 0; (size_t)ch0 + k * stride < R.nRounds; k++)
-   for (int c = 0; c < nCtx; c++) {
+  const size_t kEnd = uniform64(R.nRounds + (size_t)(nPh - 1) * stride);
+  for (size_t k = 0; (size_t)ch0 + k * stride < kEnd; k++)
+   for (int q = 0; q < (role == 3 ? 3 : nCtx); q++) {     // (q: the channel of a pairing workgroup, or the phase of role 3)
+    const int c = role == 3 ? 0 : q, ph = role == 3 ? q : 0;
     cx.select(c ? sh1 : sh0, ch0 + c);
-    const size_t g = (size_t)cx.ch + k * stride;
+    const int rl = role == 3 ? ph : role;
+    if (k < (size_t)ph) continue;
+    const size_t kk = k - (size_t)ph;
+    const size_t g = (size_t)cx.ch + kk * stride;
     if (g >= R.nRounds) continue;
-    const bool first = k == 0;
+    const bool first = kk == 0;
     cx.stepBytes = (uint32_t)(R.pieceMax(g) * sizeof(T));
-    if (role == 0) {
+    if (rl == 0) {
       cx.auxSend = words && first;
       cx.step(0, 0, peers, 0, [&]() {
         // all n-1 pieces in one fused pass when they have the same length and need no scaling
@@ -1251,13 +1260,13 @@ __device__ __forceinline__ void directAllReduce(Ctx& cx, LdsChan* sh0, LdsChan* 
           rcWG<T, OP, RC_SEND>(a, ne, cx.tid, cx.nthr);
         }
       });
-    } else if (role == 1) {
+    } else if (rl == 1) {
       cx.auxRecv = words && first && w.peerRegs;
       cx.auxSend = words && first;
       cx.step(peers, 0, peers, 1, [&]() {
         if (first && words) {
-          if (cx.tid < n && cx.tid != r) {
-            const int p = cx.tid;
+          const int p = Ctx::freshLane(cx.tid);      // (computed here, not kept in a register across every round)
+          if (p < n && p != r) {
             const uint64_t base = regBaseOf(cx.comm, p, w.peerRegs ? cx.sh->auxIn[p] : 0);
             cx.sh->directBase[p] = base;
             cx.sh->auxOut[p] = base ? RA_AUX_DIRECT : 0;
@@ -2566,7 +2575,10 @@ __global__ __launch_bounds__(1024) void raCollKernel(const RaDevComm* __restrict
   if constexpr (K == RA_K_DIRECT_ALLREDUCE) {
     LdsChan* const sh1 = RA_LDS_CHAN(shB);
     int role = blockIdx.x / w.nChannels, ch0 = blockIdx.x % w.nChannels, nCtx = 1;
-    if (w.pairRoles) {
+    if (w.pairRoles == 2) {
+      // one workgroup per channel walks all three roles (directAllReduce, role 3)
+      role = 3; ch0 = (int)blockIdx.x;
+    } else if (w.pairRoles) {
       // all-pairs all-reduce, two ranks
       const int half = w.nChannels / 2, b = (int)blockIdx.x;
       if (b >= half && b < half + w.nChannels) { role = 1; ch0 = b - half; }

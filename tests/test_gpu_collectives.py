@@ -20,11 +20,14 @@ from testbed import COLL_ALLGATHER, COLL_ALLREDUCE, COLL_BROADCAST, COLL_REDUCE,
 pytestmark = pytest.mark.gpu
 
 ALGOS = {"Direct": ex.ALGO_DIRECT, "Ring": ex.ALGO_RING, "Tree": ex.ALGO_TREE, "OneExchange": ex.ALGO_DIRECT,
-         "TwoExchange": ex.ALGO_DIRECT}
+         "TwoExchange": ex.ALGO_DIRECT, "DirectOneWorkgroup": ex.ALGO_DIRECT}
 # "Direct": the three-phase all-pairs schedule at every size; "OneExchange" / "TwoExchange": every all-reduce above the
 # low-latency limit as one exchange / as two (the planner's choices for mid-size payloads, here forced for all sizes; two
-# exchanges exist for more than two ranks); other tests run the default mix.
+# exchanges exist for more than two ranks); "DirectOneWorkgroup": the three-phase schedule with one workgroup per channel
+# walking all three roles (RCCL_AMD_FUSED_ROLES=1); other tests run the default mix.
 ALGO_ENV = {"Direct": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"},
+            "DirectOneWorkgroup": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0",
+                                   "RCCL_AMD_FUSED_ROLES": "1"},
             "TwoExchange": {"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": str(64 << 20)},
             "Ring": {"NCCL_ALGO": "Ring", "RCCL_AMD_ONESHOT_MAX_BYTES": None},
             "Tree": {"NCCL_ALGO": "Tree", "RCCL_AMD_ONESHOT_MAX_BYTES": None},
@@ -518,6 +521,21 @@ def test_registered_receive_buffers_are_written_directly(bed):
         for r in range(n):
             assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
             assert stats[r]["direct_pieces"] == 0 and stats[r]["fifo_pieces"] > 0, (r, stats[r])
+    # the same with one workgroup per channel walking all three roles: all registered, only rank 0, none
+    bed.init_comms({"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0", "RCCL_AMD_FUSED_ROLES": "1"})
+    for outs, stats in bed.run_registered(orc.F32, orc.SUM, count, ins, runs=2):
+        for r in range(n):
+            assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+            assert stats[r]["direct_pieces"] > 0 and stats[r]["fifo_pieces"] == 0, (r, stats[r])
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[0])
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+    assert stats[0]["direct_pieces"] == 0 and all(stats[r]["direct_pieces"] > 0 for r in range(1, n))
+    (outs, stats), = bed.run_registered(orc.F32, orc.SUM, count, ins, register_ranks=[])
+    for r in range(n):
+        assert ex.check(orc.F32, outs[r], want, exact=True) is None, r
+        assert stats[r]["direct_pieces"] == 0 and stats[r]["fifo_pieces"] > 0, (r, stats[r])
+    bed.init_comms({"NCCL_ALGO": None})
 
 
 def test_registered_all_gather_writes_blocks_directly(bed):

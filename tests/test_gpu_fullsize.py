@@ -190,6 +190,8 @@ ODD_ENVS = {
     "default": {"NCCL_ALGO": None, "NCCL_PROTO": None},
     "DirectFifo": {"NCCL_ALGO": "Direct", "NCCL_PROTO": "Simple", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0"},
     "TwoExchange": {"NCCL_ALGO": "Direct", "NCCL_PROTO": "Simple", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": str(64 << 20)},
+    "DirectFifoOneWorkgroup": {"NCCL_ALGO": "Direct", "NCCL_PROTO": "Simple", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0",
+                               "RCCL_AMD_FUSED_ROLES": "1"},
     "Ring+LL": {"NCCL_ALGO": "Ring", "NCCL_PROTO": "LL"},
     "Tree+LL": {"NCCL_ALGO": "Tree", "NCCL_PROTO": "LL"},
     "Ring": {"NCCL_ALGO": "Ring", "NCCL_PROTO": "Simple"},

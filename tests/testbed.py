@@ -699,7 +699,7 @@ class TestBed:
         if blocking is not None:
             env = dict(env or {})
             env["__blocking__"] = blocking
-        env = {"RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None, **(env or {})}     # limits set for one test do not leak into the next
+        env = {"RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None, "RCCL_AMD_FUSED_ROLES": None, **(env or {})}     # limits set for one test do not leak into the next
         self.destroy_comms()
         if len(self.answered) < self.nranks:
             self._all("ping", [None] * self.nranks)      # every child is past its imports before any rank waits for the others

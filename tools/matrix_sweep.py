@@ -29,6 +29,7 @@ OPS = [orc.SUM, orc.PROD, orc.MAX, orc.MIN, orc.AVG]
 FIFO = {"RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0", "NCCL_PROTO": None}
 CONFIGS = [
     ("all-pairs FIFOs", {"NCCL_ALGO": "Direct", **FIFO}, (COLL_ALLREDUCE, COLL_REDUCESCATTER, COLL_REDUCE)),
+    ("all-pairs FIFOs, one workgroup per channel", {"NCCL_ALGO": "Direct", "RCCL_AMD_FUSED_ROLES": "1", **FIFO}, (COLL_ALLREDUCE,)),
     ("ring", {"NCCL_ALGO": "Ring", **FIFO}, (COLL_ALLREDUCE, COLL_REDUCESCATTER)),
     ("chain", {"NCCL_ALGO": "Tree", **FIFO}, (COLL_ALLREDUCE,)),
     ("default choice", {"NCCL_ALGO": None, "RCCL_AMD_ONESHOT_MAX_BYTES": None, "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": None, "NCCL_PROTO": None},
