@@ -471,6 +471,17 @@ def test_hip_graph_capture_and_replay(bed):
     ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
     outs = bed.run(COLL_REDUCE, orc.F32, orc.SUM, count, ins, count * 4, root=0, graph=True)
     assert ex.check(orc.F32, outs[0], orc.device_fold(orc.F32, orc.SUM, ins), exact=True) is None
+    # the three-phase FIFO schedule replayed, several rounds per channel, in both role layouts
+    count = (1 << 20) + 1028
+    ins = [orc.fill_pattern(orc.F32, count, r) for r in range(n)]
+    for fused in (None, "1"):
+        bed.init_comms({"NCCL_ALGO": "Direct", "RCCL_AMD_ONESHOT_MAX_BYTES": "0", "RCCL_AMD_TWO_EXCHANGE_MAX_BYTES": "0", "RCCL_AMD_FUSED_ROLES": fused})
+        plan = bed.plan(COLL_ALLREDUCE, count, orc.F32)
+        assert plan["proto"] == 0
+        outs = bed.run(COLL_ALLREDUCE, orc.F32, orc.AVG, count, ins, count * 4, graph=True)
+        for o in outs:
+            assert ex.check(orc.F32, o, ex.allreduce(orc.F32, orc.AVG, ins, plan), exact=True) is None
+    bed.init_comms({"NCCL_ALGO": None})
 
 
 def test_registered_receive_buffers_are_written_directly(bed):
