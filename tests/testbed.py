@@ -195,11 +195,14 @@ def _child(rank, nranks, device, conn, env):
                     conn.send(("ok", None))
                 else:
                     sub.wait_ready()
-                    src = (torch.arange(count, dtype=torch.int32) + 1000 * rank).cuda()
-                    dst = torch.zeros(count, dtype=torch.int32, device="cuda")
+                    src_b = _DevBuf(ra, 0, image=(np.arange(count, dtype=np.int32) + 1000 * rank), arena=True)
+                    dst_b = _DevBuf(ra, count * 4, fill=0, arena=True)
                     torch.cuda.synchronize()
-                    sub.all_reduce(src, dst, count, ra.ncclInt32, ra.ncclSum, stream)
+                    sub.all_reduce(src_b.data_ptr(), dst_b.data_ptr(), count, ra.ncclInt32, ra.ncclSum, stream)
                     stream.synchronize()
+                    dst = torch.from_numpy(dst_b.read().view(np.int32).copy())
+                    src_b.free(); dst_b.free()
+                    _DevBuf.arena_used = 0
                     # (the channels the new communicator would use for a large all-reduce: ncclConfig_t::maxCTAs bounds them)
                     big = sub.plan_info(COLL_ALLREDUCE, 1 << 28, ra.ncclFloat32)["nChannels"] if sub.count() > 1 else 0
                     res = (sub.count(), sub.user_rank(), sub.async_error(), dst.cpu().numpy().tobytes(), big)
@@ -617,9 +620,9 @@ def _child(rank, nranks, device, conn, env):
             elif cmd == "interleave":
                 # args: dict(dtype, op, count, a(bytes), b(bytes)): first(a) second(b) first(b) second(a) on one stream
                 a = args
-                ta = _DevBuf(ra, 0, image=np.frombuffer(a["a"], dtype=np.uint8))
-                tb = _DevBuf(ra, 0, image=np.frombuffer(a["b"], dtype=np.uint8))
-                outs = [_DevBuf(ra, ta.numel(), fill=0xA5) for _ in range(4)]
+                ta = _DevBuf(ra, 0, image=np.frombuffer(a["a"], dtype=np.uint8), arena=True)
+                tb = _DevBuf(ra, 0, image=np.frombuffer(a["b"], dtype=np.uint8), arena=True)
+                outs = [_DevBuf(ra, ta.numel(), fill=0xA5, arena=True) for _ in range(4)]
                 torch.cuda.synchronize()
                 for k, (c, src) in enumerate([(comm, ta), (comm2, tb), (comm, tb), (comm2, ta)]):
                     c.all_reduce(src.data_ptr(), outs[k].data_ptr(), a["count"], a["dtype"], a["op"], stream)
@@ -628,6 +631,7 @@ def _child(rank, nranks, device, conn, env):
                 got = [o.read().tobytes() for o in outs]
                 for b in [ta, tb] + outs:
                     b.free()
+                _DevBuf.arena_used = 0
                 conn.send(("ok", (errs, got)))
             elif cmd == "second_destroy":
                 comm2.destroy()
