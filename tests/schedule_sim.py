@@ -174,12 +174,31 @@ def direct_allreduce(n, r, role, channels, plan, count, out):
     R = Rounds(count, plan["chunkElems"], plan["lastChunkElems"], n)
     C = plan["nChannels"]
     peers = [p for p in range(n) if p != r]
+    if role == 3:
+        # one workgroup per channel walks all three roles, skewed by one round each: scatter of round k, reduce of round
+        # k - 1, gather of round k - 2 (directAllReduce, role 3)
+        ch = channels[0]
+        k = 0
+        while ch + (k - 2) * C < R.nrounds:
+            for ph in range(3):
+                if k - ph < 0 or ch + (k - ph) * C >= R.nrounds:
+                    continue
+                yield from _direct_allreduce_step(n, r, ph, ch, ch + (k - ph) * C, R, peers, out)
+            k += 1
+        return
     k = 0
     while channels[0] + k * C < R.nrounds:
         for ch in channels:
             g = ch + k * C
             if g >= R.nrounds:
                 continue
+            yield from _direct_allreduce_step(n, r, role, ch, g, R, peers, out)
+        k += 1
+
+
+def _direct_allreduce_step(n, r, role, ch, g, R, peers, out):
+    if True:
+        if True:
             if role == 0:
                 def body(read, write, g=g):
                     for p in peers:
@@ -206,7 +225,6 @@ def direct_allreduce(n, r, role, channels, plan, count, out):
                         assert got[0] == off and got[1] == ne, ("gather", r, "round", g, "from", p, got, (off, ne))
                         out.put(r, off, ne, got[2])
                 yield Step(r, ch, [(p, 1) for p in peers], [], body)
-        k += 1
 
 
 def direct_reduce_scatter(n, r, role, ch, plan, count, out, elem_size=4):
@@ -447,7 +465,7 @@ def chain_allreduce(n, r, role, ch, plan, count, rings, out, elem_size=4):
 
 
 # ------------------------------------------------------------------ one launch on every rank
-def launch(net, coll, algo, plan, count, elem_size, rings, cus=256):
+def launch(net, coll, algo, plan, count, elem_size, rings, cus=256, one_workgroup=False):
     """All workgroups of one collective launch on all ranks, run to completion.  `count`: elements (all-reduce), elements
     per rank (reduce-scatter), elements per rank (all-gather; moved as bytes).  Returns (Outputs, steps run)."""
     n = net.n
@@ -456,7 +474,12 @@ def launch(net, coll, algo, plan, count, elem_size, rings, cus=256):
     progs = []
     for r in range(n):
         wgs = 0
-        if algo == DIRECT and coll == ALLREDUCE:
+        if algo == DIRECT and coll == ALLREDUCE and one_workgroup:
+            # RCCL_AMD_FUSED_ROLES=1: grid = channels
+            for ch in range(C):
+                progs.append(direct_allreduce(n, r, 3, [ch], plan, count, out))
+            wgs = plan["grid"]
+        elif algo == DIRECT and coll == ALLREDUCE:
             pair = n == 2 and C >= 2 and C % 2 == 0                 # pairsRoles in enqueue.cc
             for ch in range(C):
                 progs.append(direct_allreduce(n, r, 1, [ch], plan, count, out))

@@ -119,3 +119,26 @@ def test_the_model_notices_a_credit_deadlock_and_a_misplaced_piece():
     with pytest.raises(AssertionError):
         sim.run(net, progs)
         out.check(1 << 22, frozenset(range(n)))
+
+
+def test_one_workgroup_per_channel_all_reduce():
+    """RCCL_AMD_FUSED_ROLES=1: one workgroup per channel runs scatter of round k, reduce of round k - 1 and gather of round
+    k - 2.  With the layout's two slots per FIFO it completes at every rank count and size, same FIFOs reused by a ragged
+    second launch and by the three-role form; with ONE slot per FIFO the same sequence waits on itself (the scatter of
+    round k needs the credit of the peers' reduce of round k - 1, which they run behind their own scatter of round k),
+    and the model says so."""
+    for n in (3, 4, 5, 8):
+        rings = _rings(n)
+        net = sim.Net(n)
+        for count in (1 << 28, (1 << 24) + 12345, 70001, 1 << 20):
+            for channels in (_channels(n), 112):
+                plan = ra.plan_for_config(n, sim.ALLREDUCE, count, F32, algo=sim.DIRECT, max_channels=channels, slot_bytes=SLOT)
+                plan = dict(plan, grid=plan["nChannels"])
+                out, _ = sim.launch(net, sim.ALLREDUCE, sim.DIRECT, plan, count, 4, rings, one_workgroup=True)
+                out.check(count, frozenset(range(n)))
+                assert net.max_depth <= net.nslots
+            _run(net, n, sim.ALLREDUCE, sim.DIRECT, count, F32, rings)         # the three-role form continues the same FIFOs
+    net1 = sim.Net(4, nslots=1)
+    plan = ra.plan_for_config(4, sim.ALLREDUCE, 1 << 24, F32, algo=sim.DIRECT, max_channels=32, slot_bytes=SLOT)
+    with pytest.raises(sim.Deadlock):
+        sim.launch(net1, sim.ALLREDUCE, sim.DIRECT, dict(plan, grid=plan["nChannels"]), 1 << 24, 4, _rings(4), one_workgroup=True)
